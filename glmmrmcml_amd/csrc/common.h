@@ -1,0 +1,109 @@
+// common.h -- error plumbing and device-buffer helpers for libglmmr_mcml_hip.
+// gfx950 (MI355X) only; no CUDA shims, no dual paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace mcml {
+
+// error codes returned through the C ABI (never throw across it)
+enum : int {
+    MCML_OK = 0,
+    MCML_EINVAL = -1,       // bad argument / shape
+    MCML_EUNSUPPORTED = -2, // family/link or covariance function not built
+    MCML_ENOTPD = -3,       // covariance block not positive definite
+    MCML_ESINGULAR = -4,    // singular X'WX in MCNR
+    MCML_EHIP = -5,         // HIP runtime error
+    MCML_ENODEVICE = -6,    // no MI355X visible: the product has no CPU fallback
+    MCML_ENOMEM = -7,
+};
+
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define MCML_HIP(expr)                                                              \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            ::mcml::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),\
+                              __FILE__, __LINE__);                                  \
+            return ::mcml::MCML_EHIP;                                               \
+        }                                                                           \
+    } while (0)
+
+#define MCML_TRY(expr)                       \
+    do {                                     \
+        int _rc = (expr);                    \
+        if (_rc != ::mcml::MCML_OK) return _rc; \
+    } while (0)
+
+#define MCML_REQUIRE(cond, ...)              \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::mcml::set_error(__VA_ARGS__);  \
+            return ::mcml::MCML_EINVAL;      \
+        }                                    \
+    } while (0)
+
+static inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+static inline size_t round_up_sz(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Leading dimension used for every device matrix: a multiple of 16 doubles
+// (128 B) so that any column starts on a full cache line and 16-byte vector
+// loads of row pairs are always aligned.
+static inline int pad_ld(int rows) { return round_up(rows < 1 ? 1 : rows, 16); }
+
+// Owning device allocation.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    }
+    int ensure(size_t nbytes) {
+        if (nbytes <= bytes) return MCML_OK;
+        release();
+        // +256 B slack: vector loads at a ragged edge may touch the pad
+        hipError_t e = hipMalloc(&p, nbytes + 256);
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(e));
+            return MCML_ENOMEM;
+        }
+        bytes = nbytes;
+        return MCML_OK;
+    }
+    double* d() const { return static_cast<double*>(p); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// Column-major device matrix with padded leading dimension.
+struct DevMat {
+    DevBuf buf;
+    int rows = 0, cols = 0, ld = 0;
+    int alloc(int r, int c) {
+        int nld = pad_ld(r);
+        MCML_TRY(buf.ensure(sizeof(double) * (size_t)nld * (size_t)(c < 1 ? 1 : c)));
+        rows = r; cols = c; ld = nld;
+        return MCML_OK;
+    }
+    double* d() const { return buf.d(); }
+    double* at(int i, int j) const { return buf.d() + i + (size_t)j * ld; }
+};
+
+// host (ldh) <-> device (padded ld) copies of a column-major matrix
+int upload_matrix(DevMat& dst, const double* host, int rows, int cols, int ldh, hipStream_t s);
+int download_matrix(double* host, int ldh, const double* dev, int ldd, int rows, int cols,
+                    hipStream_t s);
+
+}  // namespace mcml

@@ -1,0 +1,74 @@
+// debug_hooks.hip -- C-ABI test/bench hooks for the GEMM building block
+// (declared in include/glmmr_mcml_c.h under "test hooks").
+#include "dgemm_mfma.h"
+
+using namespace mcml;
+
+extern "C" int glmmr_mcml_dbg_dgemm(int M, int N, int K, const double* A, int lda,
+                                    const double* B, int ldb, int b_nmajor,
+                                    double alpha, double beta, double* C, int ldc,
+                                    int lower_only, int force_tile)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device: libglmmr_mcml_hip has no CPU fallback");
+        return MCML_ENODEVICE;
+    }
+    hipStream_t s = nullptr;
+    DevMat dA, dB, dC;
+    MCML_TRY(upload_matrix(dA, A, M, K, lda, s));
+    if (b_nmajor) MCML_TRY(upload_matrix(dB, B, N, K, ldb, s));
+    else MCML_TRY(upload_matrix(dB, B, K, N, ldb, s));
+    MCML_TRY(upload_matrix(dC, C, M, N, ldc, s));
+    EpiAxpby epi{dC.d(), dC.ld, alpha, beta};
+    int rc = b_nmajor ? launch_gemm<true>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi,
+                                          lower_only != 0, force_tile)
+                      : launch_gemm<false>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi,
+                                           lower_only != 0, force_tile);
+    MCML_TRY(rc);
+    MCML_TRY(download_matrix(C, ldc, dC.d(), dC.ld, M, N, s));
+    return MCML_OK;
+}
+
+// times `iters` launches of the M x N x K product on resident random operands
+extern "C" int glmmr_mcml_dbg_dgemm_bench(int M, int N, int K, int b_nmajor, int iters,
+                                          int force_tile, double* ms_per_launch)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device: libglmmr_mcml_hip has no CPU fallback");
+        return MCML_ENODEVICE;
+    }
+    hipStream_t s = nullptr;
+    std::vector<double> hA((size_t)M * K), hB((size_t)K * N), hC((size_t)M * N, 0.0);
+    uint64_t x = 88172645463325252ULL;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (double)(x >> 11) / 9007199254740992.0 * 2 - 1; };
+    for (auto& v : hA) v = rnd();
+    for (auto& v : hB) v = rnd();
+    DevMat dA, dB, dC;
+    MCML_TRY(upload_matrix(dA, hA.data(), M, K, M, s));
+    if (b_nmajor) MCML_TRY(upload_matrix(dB, hB.data(), N, K, N, s));
+    else MCML_TRY(upload_matrix(dB, hB.data(), K, N, K, s));
+    MCML_TRY(upload_matrix(dC, hC.data(), M, N, M, s));
+    EpiAxpby epi{dC.d(), dC.ld, 1.0, 0.0};
+    auto go = [&]() {
+        return b_nmajor ? launch_gemm<true>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, false, force_tile)
+                        : launch_gemm<false>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, false, force_tile);
+    };
+    for (int i = 0; i < 3; i++) MCML_TRY(go());
+    hipEvent_t e0, e1;
+    MCML_HIP(hipEventCreate(&e0));
+    MCML_HIP(hipEventCreate(&e1));
+    MCML_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; i++) MCML_TRY(go());
+    MCML_HIP(hipEventRecord(e1, s));
+    MCML_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    MCML_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return MCML_OK;
+}
+
+extern "C" const char* glmmr_mcml_last_error(void) { return mcml::last_error(); }

@@ -1,0 +1,296 @@
+// dgemm_mfma.h -- the FP64 matrix-core GEMM every dense contraction of the MCML
+// hot path runs on (HMC forward/backward products, Z*L, Z*u, L*V, the trailing
+// updates of the Cholesky factorisation and of the triangular solves).
+//
+//   C(M x N) = epilogue( A(M x K) * B(K x N) )
+//
+// A is column-major (M contiguous).  B is either K-major (column-major K x N,
+// as the Q x m sample matrices are) or N-major (B^T stored column-major, as the
+// L21 panels of the Cholesky update are).  All operands f64.
+//
+// CDNA4 mapping (one 256-thread workgroup = 4 waves = one wave per SIMD):
+//   * v_mfma_f64_16x16x4_f64, 64-lane waves, operands swapped so that the MFMA's
+//     D tile is C^T: lane l, reg r holds C[m = l&15][n = (l>>4)+4r], i.e. each
+//     16-lane group stores 128 contiguous bytes of a column of C.
+//   * block tile (32*TM) x (32*TN), K step 16, wave tile (16*TM) x (16*TN);
+//     TM=5,TN=4 gives 160 x 128 tiles = exactly 256 workgroups for the
+//     5000 x 1024 products of the n=5000, m=1024 configuration.
+//   * operands staged global -> VGPR (16-B loads) -> LDS, double buffered, one
+//     barrier per K step; the next tile's global loads are issued before the
+//     MFMAs of the current one.
+//   * LDS rows padded so that the two 16-lane halves of a ds_read_b64 land in
+//     disjoint bank halves (A rows: stride = 16 mod 32 doubles; K-major B rows:
+//     18 doubles).
+//   * blockIdx -> tile map is XCD-aware: each XCD (blockIdx % 8) owns a
+//     contiguous band of row tiles, so the A band and the B panels it shares
+//     stay in that XCD's L2.
+#pragma once
+#include "common.h"
+
+namespace mcml {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int GEMM_BK = 16;
+
+struct GemmP {
+    int M, N, K;
+    const double* A; int lda;   // A[i + k*lda]
+    const double* B; int ldb;   // K-major: B[k + j*ldb];  N-major: B[j + k*ldb]
+    int gm, gn;                 // tile grid
+    int lower_only;             // skip tiles that lie strictly above the diagonal
+};
+
+// WTM x WTN: 16x16 MFMA tiles per wave; WM x WN: waves per workgroup.
+template <int WTM, int WTN, int WM, int WN, bool BNMAJOR>
+struct GemmCfg {
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int BM = 16 * WTM * WM, BN = 16 * WTN * WN;
+    static constexpr int SA = BM + 16;
+    static constexpr int SB = BNMAJOR ? (BN + 16) : (GEMM_BK + 2);
+    static constexpr int A_TILE = GEMM_BK * SA;
+    static constexpr int B_TILE = BNMAJOR ? GEMM_BK * SB : BN * SB;
+    static constexpr size_t LDS_BYTES = sizeof(double) * 2 * (A_TILE + B_TILE);
+    // 16-byte staging loads per thread (ceil)
+    static constexpr int A_VEC = GEMM_BK * BM / 2, B_VEC = GEMM_BK * BN / 2;
+    static constexpr int A_LD = (A_VEC + THREADS - 1) / THREADS;
+    static constexpr int B_LD = (B_VEC + THREADS - 1) / THREADS;
+};
+
+// Epilogues receive the wave's accumulator fragment:
+//   acc[i][j][r] = C[mB + 16 i + (lane & 15)][nB + 16 j + (lane >> 4) + 4 r]
+#define MCML_EPI_FOREACH(TM_, TN_)                                   \
+    _Pragma("unroll") for (int i = 0; i < TM_; ++i)                  \
+    _Pragma("unroll") for (int j = 0; j < TN_; ++j)                  \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r)
+
+struct EpiAxpby {   // C = alpha*A*B + beta*C
+    double* C; int ldc; double alpha, beta;
+    template <int TM, int TN>
+    __device__ __forceinline__ void operator()(d4 (&acc)[TM][TN], int mB, int nB, int lane,
+                                               int M, int N, int /*rowslot*/) const {
+        MCML_EPI_FOREACH(TM, TN) {
+            int m = mB + 16 * i + (lane & 15), n = nB + 16 * j + (lane >> 4) + 4 * r;
+            if (m < M && n < N) {
+                double* c = C + m + (size_t)n * ldc;
+                double v = alpha * acc[i][j][r];
+                if (beta != 0.0) v += beta * (*c);
+                *c = v;
+            }
+        }
+    }
+};
+
+template <int WTM, int WTN, int WM, int WN, bool BNMAJOR, class Epi>
+__global__ __launch_bounds__(64 * WM * WN) void dgemm_mfma_kernel(GemmP p, Epi epi)
+{
+    using Cfg = GemmCfg<WTM, WTN, WM, WN, BNMAJOR>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, SA = Cfg::SA, SB = Cfg::SB, NT = Cfg::THREADS;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;
+    double* Bs = smem + 2 * Cfg::A_TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WN, wc = wave - wr * WN;
+
+    // XCD-aware, bijective blockIdx -> tile map
+    const int nblk = p.gm * p.gn;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int bi = nid / p.gn, bj = nid - bi * p.gn;
+    if (p.lower_only && (bi + 1) * BM <= bj * BN) return;
+    const int m0 = bi * BM, n0 = bj * BN;
+
+    d2 ra[Cfg::A_LD], rb[Cfg::B_LD];
+    bool oka[Cfg::A_LD], okb[Cfg::B_LD], okb1[Cfg::B_LD];
+
+    // Guarded loads are branch-free: the address is clamped into the operand
+    // (always readable) and the zero-select is applied only in store_tiles(),
+    // i.e. after the MFMA block, so the loads' latency hides under the MFMAs.
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < Cfg::A_LD; ++i) {
+            int idx = tid + i * NT;
+            if (Cfg::A_VEC % NT != 0 && idx >= Cfg::A_VEC) idx = Cfg::A_VEC - 1;
+            int kr = idx / (BM / 2), mp = idx - kr * (BM / 2);
+            int m = m0 + 2 * mp, k = k0 + kr;
+            bool ok = (m < p.M) && (k < p.K);
+            int mc = ok ? m : 0, kc = ok ? k : 0;
+            ra[i] = *reinterpret_cast<const d2*>(p.A + mc + (size_t)kc * p.lda);
+            oka[i] = ok;
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::B_LD; ++j) {
+            int idx = tid + j * NT;
+            if (Cfg::B_VEC % NT != 0 && idx >= Cfg::B_VEC) idx = Cfg::B_VEC - 1;
+            if (BNMAJOR) {
+                int kr = idx / (BN / 2), np = idx - kr * (BN / 2);
+                int n = n0 + 2 * np, k = k0 + kr;
+                bool ok = (n < p.N) && (k < p.K);
+                int nc = ok ? n : 0, kc = ok ? k : 0;
+                rb[j] = *reinterpret_cast<const d2*>(p.B + nc + (size_t)kc * p.ldb);
+                okb[j] = ok; okb1[j] = ok;
+            } else {
+                int ncol = idx >> 3, kp = idx & 7;
+                int n = n0 + ncol, k = k0 + 2 * kp;
+                bool ok = (n < p.N) && (k < p.K);
+                int nc = ok ? n : 0, kc = ok ? k : 0;
+                rb[j] = *reinterpret_cast<const d2*>(p.B + kc + (size_t)nc * p.ldb);
+                okb[j] = ok; okb1[j] = ok && (k + 1 < p.K);
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        double* as = As + buf * Cfg::A_TILE;
+        double* bs = Bs + buf * Cfg::B_TILE;
+#pragma unroll
+        for (int i = 0; i < Cfg::A_LD; ++i) {
+            int idx = tid + i * NT;
+            if (Cfg::A_VEC % NT == 0 || idx < Cfg::A_VEC) {
+                int kr = idx / (BM / 2), mp = idx - kr * (BM / 2);
+                d2 v = oka[i] ? ra[i] : d2{0.0, 0.0};
+                *reinterpret_cast<d2*>(as + kr * SA + 2 * mp) = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::B_LD; ++j) {
+            int idx = tid + j * NT;
+            if (Cfg::B_VEC % NT == 0 || idx < Cfg::B_VEC) {
+                d2 v;
+                v[0] = okb[j] ? rb[j][0] : 0.0;
+                v[1] = okb1[j] ? rb[j][1] : 0.0;
+                if (BNMAJOR) {
+                    int kr = idx / (BN / 2), np = idx - kr * (BN / 2);
+                    *reinterpret_cast<d2*>(bs + kr * SB + 2 * np) = v;
+                } else {
+                    int ncol = idx >> 3, kp = idx & 7;
+                    *reinterpret_cast<d2*>(bs + ncol * SB + 2 * kp) = v;
+                }
+            }
+        }
+    };
+
+    d4 acc[WTM][WTN];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+    const int nk = (p.K + GEMM_BK - 1) / GEMM_BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int l15 = lane & 15, lk = lane >> 4;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) load_tiles((kt + 1) * GEMM_BK);
+        __builtin_amdgcn_sched_barrier(0);   // loads are issued, not consumed, above here
+        const double* as = As + cur * Cfg::A_TILE + wr * 16 * WTM + l15;
+        const double* bs = BNMAJOR ? (Bs + cur * Cfg::B_TILE + wc * 16 * WTN + l15)
+                                   : (Bs + cur * Cfg::B_TILE + (wc * 16 * WTN + l15) * SB);
+#pragma unroll
+        for (int ks = 0; ks < GEMM_BK / 4; ++ks) {
+            const int kk = 4 * ks + lk;
+            double a[WTM], b[WTN];
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) a[i] = as[kk * SA + 16 * i];
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) b[j] = BNMAJOR ? bs[kk * SB + 16 * j] : bs[16 * j * SB + kk];
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                for (int j = 0; j < WTN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the loads' first use stays below the MFMAs
+        if (more) store_tiles(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    epi(acc, m0 + wr * 16 * WTM, n0 + wc * 16 * WTN, lane, p.M, p.N, bi * WM + wr);
+}
+
+// Tile variants: id -> (block tile, waves)
+//   0: 160 x 128, 8 waves (5x2 MFMA tiles per wave)   1: 128 x 128, 8 waves (4x2)
+//   2: 128 x  64, 4 waves (4x2)                        3:  64 x  64, 4 waves (2x2)
+struct TileChoice { int id; };
+static const struct { int bm, bn; double eff; } kTileTab[4] = {
+    {160, 128, 1.00}, {128, 128, 0.97}, {128, 64, 0.90}, {64, 64, 0.80}};
+
+// Smallest estimated time: workgroups are dealt 256 at a time (one per CU);
+// smaller tiles pay more staging per flop.
+static inline TileChoice pick_tile(int M, int N)
+{
+    TileChoice best{3};
+    double bestc = 1e300;
+    for (int id = 0; id < 4; ++id) {
+        long gm = (M + kTileTab[id].bm - 1) / kTileTab[id].bm, gn = (N + kTileTab[id].bn - 1) / kTileTab[id].bn;
+        long rounds = (gm * gn + 255) / 256;
+        double cost = (double)rounds * kTileTab[id].bm * kTileTab[id].bn / kTileTab[id].eff;
+        if (cost < bestc) { bestc = cost; best = TileChoice{id}; }
+    }
+    return best;
+}
+
+template <int WTM, int WTN, int WM, int WN, bool BNMAJOR, class Epi>
+static inline int launch_gemm_tile(hipStream_t s, GemmP p, const Epi& epi)
+{
+    using Cfg = GemmCfg<WTM, WTN, WM, WN, BNMAJOR>;
+    p.gm = (p.M + Cfg::BM - 1) / Cfg::BM;
+    p.gn = (p.N + Cfg::BN - 1) / Cfg::BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MCML_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&dgemm_mfma_kernel<WTM, WTN, WM, WN, BNMAJOR, Epi>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dgemm_mfma_kernel<WTM, WTN, WM, WN, BNMAJOR, Epi>), dim3(p.gm * p.gn),
+                       dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, p, epi);
+    MCML_HIP(hipGetLastError());
+    return MCML_OK;
+}
+
+// number of row slots an epilogue that keeps per-(row slot, column) partials needs
+static inline int gemm_row_slots(int M, int tile_id)
+{
+    int bm = kTileTab[tile_id].bm;
+    return ((M + bm - 1) / bm) * 2;   // every variant has WM = 2
+}
+
+// Host-side shape contract of the kernel (checked before every launch: a
+// faulting kernel can take the whole node down).
+static inline int check_gemm_args(const GemmP& p)
+{
+    MCML_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "dgemm: empty shape %dx%dx%d", p.M, p.N, p.K);
+    MCML_REQUIRE(p.A && p.B, "dgemm: null operand");
+    MCML_REQUIRE((p.lda & 1) == 0 && (p.ldb & 1) == 0, "dgemm: odd leading dimension");
+    MCML_REQUIRE(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0,
+                 "dgemm: operand not 16-byte aligned");
+    MCML_REQUIRE(p.lda >= p.M, "dgemm: lda %d < M %d", p.lda, p.M);
+    return MCML_OK;
+}
+
+template <bool BNMAJOR, class Epi>
+static inline int launch_gemm(hipStream_t s, int M, int N, int K, const double* A, int lda,
+                              const double* B, int ldb, const Epi& epi, bool lower_only = false,
+                              int force_tile = -1)
+{
+    GemmP p{M, N, K, A, lda, B, ldb, 0, 0, lower_only ? 1 : 0};
+    MCML_TRY(check_gemm_args(p));
+    MCML_REQUIRE(BNMAJOR ? ldb >= N : ldb >= K, "dgemm: ldb %d too small", ldb);
+    int id = force_tile >= 0 ? force_tile : pick_tile(M, N).id;
+    switch (id) {
+    case 0: return launch_gemm_tile<5, 2, 2, 4, BNMAJOR, Epi>(s, p, epi);
+    case 1: return launch_gemm_tile<4, 2, 2, 4, BNMAJOR, Epi>(s, p, epi);
+    case 2: return launch_gemm_tile<4, 2, 2, 2, BNMAJOR, Epi>(s, p, epi);
+    default: return launch_gemm_tile<2, 2, 2, 2, BNMAJOR, Epi>(s, p, epi);
+    }
+}
+
+}  // namespace mcml

@@ -1,0 +1,57 @@
+"""FP64 MFMA GEMM building block vs numpy float64 (GPU).  Tolerance: f64
+accumulation in a different order, |err| <= 1e-12 * sum|a||b| per element."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+dp = C.POINTER(C.c_double)
+
+
+def _gemm(A, B, Cm, alpha, beta, b_nmajor, lower_only=0, tile=-1):
+    from glmmrmcml_amd import _lib
+    L = _lib.lib()
+    M, K = A.shape
+    N = Cm.shape[1]
+    A = np.asfortranarray(A); B = np.asfortranarray(B); out = np.asfortranarray(Cm.copy())
+    rc = L.glmmr_mcml_dbg_dgemm(M, N, K, A.ctypes.data_as(dp), A.shape[0], B.ctypes.data_as(dp),
+                                B.shape[0], int(b_nmajor), C.c_double(alpha), C.c_double(beta),
+                                out.ctypes.data_as(dp), out.shape[0], lower_only, tile)
+    _lib.check(rc)
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 16, 4), (160, 128, 16), (161, 129, 17), (333, 77, 250),
+                                   (1000, 256, 999), (5, 3, 2), (640, 512, 640)])
+@pytest.mark.parametrize("b_nmajor", [0, 1])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3])
+def test_dgemm_matches_numpy(M, N, K, b_nmajor, tile):
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.normal(size=(M, K)); Bm = rng.normal(size=(K, N)); C0 = rng.normal(size=(M, N))
+    Bdev = Bm.T.copy() if b_nmajor else Bm
+    got = _gemm(A, Bdev, C0, -1.0, 1.0, b_nmajor, tile=tile)
+    want = C0 - A @ Bm
+    bound = 1e-12 * (np.abs(A) @ np.abs(Bm) + np.abs(C0))
+    assert np.all(np.abs(got - want) <= bound)
+
+
+def test_dgemm_asymmetric_identity_check():
+    """A = I with an asymmetric B catches a transposed C write"""
+    n = 48
+    B = np.arange(n * n, dtype=float).reshape(n, n)
+    got = _gemm(np.eye(n), B, np.zeros((n, n)), 1.0, 0.0, 0)
+    assert np.array_equal(got, B)
+
+
+def test_dgemm_lower_only_leaves_upper_tiles():
+    rng = np.random.default_rng(3)
+    n, k = 700, 128
+    A = rng.normal(size=(n, k)); C0 = rng.normal(size=(n, n))
+    got = _gemm(A, A, C0, -1.0, 1.0, 1, lower_only=1)
+    want = C0 - A @ A.T
+    low = np.tril_indices(n)
+    assert np.allclose(got[low], want[low], rtol=0, atol=1e-10)
+    # tiles strictly above the diagonal are untouched
+    assert np.array_equal(got[0:128, 640:], C0[0:128, 640:])

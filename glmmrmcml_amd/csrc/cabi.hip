@@ -1,0 +1,245 @@
+// cabi.hip -- the extern "C" boundary (include/glmmr_mcml_c.h).
+#include "../../include/glmmr_mcml_c.h"
+#include "ctx.h"
+
+using namespace mcml;
+
+struct glmmr_mcml_ctx { Ctx c; };
+
+static int flink_of(const char* family, const char* link)
+{
+    // mcmlmodel.h:74-87 string_to_case
+    static const char* tab[12][2] = {
+        {"poisson", "log"}, {"poisson", "identity"}, {"binomial", "logit"},
+        {"binomial", "log"}, {"binomial", "identity"}, {"binomial", "probit"},
+        {"gaussian", "identity"}, {"gaussian", "log"}, {"gamma", "log"},
+        {"gamma", "inverse"}, {"gamma", "identity"}, {"beta", "logit"}};
+    for (int i = 0; i < 12; i++)
+        if (!strcmp(family, tab[i][0]) && !strcmp(link, tab[i][1])) return i + 1;
+    return 0;
+}
+
+static int link_code_of(const char* link)
+{
+    // moremaths.h:123-129
+    if (!strcmp(link, "log")) return 1;
+    if (!strcmp(link, "identity")) return 2;
+    if (!strcmp(link, "logit")) return 3;
+    if (!strcmp(link, "probit")) return 4;
+    if (!strcmp(link, "inverse")) return 5;
+    return 0;
+}
+
+static int require_device(int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible: libglmmr_mcml_hip has no CPU fallback");
+        return MCML_ENODEVICE;
+    }
+    MCML_REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
+    MCML_HIP(hipSetDevice(device));
+    return MCML_OK;
+}
+
+extern "C" int glmmr_mcml_ctx_create(const glmmr_mcml_problem* p, const glmmr_mcml_dev_opts* o,
+                                     glmmr_mcml_ctx** out)
+{
+    MCML_REQUIRE(p && out, "ctx_create: null argument");
+    *out = nullptr;
+    MCML_TRY(require_device(o ? o->device : 0));
+    auto* h = new (std::nothrow) glmmr_mcml_ctx();
+    MCML_REQUIRE(h, "out of host memory");
+    Ctx& c = h->c;
+    auto fail = [&](int rc) { delete h; return rc; };
+    c.device = o ? o->device : 0;
+    if (o && o->stream) { c.stream = (hipStream_t)o->stream; c.own_stream = false; }
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); return fail(MCML_EHIP); }
+        c.own_stream = true;
+    }
+    c.rank = o ? o->rank : 0;
+    c.world = (o && o->world > 0) ? o->world : 1;
+    c.reduce = o ? (reduce_fn)o->reduce : nullptr;
+    c.reduce_user = o ? o->reduce_user : nullptr;
+    int rc = c.cov.parse(p->cov, p->cov_rows, p->data, p->data_len, p->eff_range, p->eff_len);
+    if (rc) return fail(rc);
+    c.Q = c.cov.N;
+    if (p->Q > 0 && p->Q != c.cov.N) {
+        set_error("Z has %d columns but the covariance blocks sum to %d", p->Q, c.cov.N);
+        return fail(MCML_EINVAL);
+    }
+    c.n = p->n; c.P = p->P;
+    if (p->n > 0) {
+        if (!(p->Z && p->X && p->y && p->family && p->link && p->P > 0)) {
+            set_error("ctx_create: n > 0 needs Z, X, y, family, link");
+            return fail(MCML_EINVAL);
+        }
+        c.flink = flink_of(p->family, p->link);
+        c.link_code = link_code_of(p->link);
+        if (!c.flink) {
+            set_error("family '%s' with link '%s' is not a known combination", p->family, p->link);
+            return fail(MCML_EUNSUPPORTED);
+        }
+        if ((rc = model_setup(c, p->Z, p->X, p->y))) return fail(rc);
+    }
+    if ((rc = mvn_setup(c))) return fail(rc);
+    *out = h;
+    return MCML_OK;
+}
+
+extern "C" int glmmr_mcml_ctx_destroy(glmmr_mcml_ctx* h)
+{
+    if (!h) return MCML_OK;
+    (void)hipSetDevice(h->c.device);
+    if (h->c.stream) (void)hipStreamSynchronize(h->c.stream);
+    hipStream_t s = h->c.own_stream ? h->c.stream : nullptr;
+    delete h;
+    if (s) (void)hipStreamDestroy(s);
+    return MCML_OK;
+}
+
+extern "C" int glmmr_mcml_set_u(glmmr_mcml_ctx* h, const double* u, int Q, int ncols, int niter)
+{
+    MCML_REQUIRE(h && u, "set_u: null argument");
+    Ctx& c = h->c;
+    MCML_REQUIRE(Q == c.Q && ncols > 0 && niter > 0 && niter <= ncols, "set_u: bad shape %d x %d (niter %d)", Q, ncols, niter);
+    MCML_HIP(hipSetDevice(c.device));
+    MCML_TRY(upload_matrix(c.U, u, Q, ncols, Q, c.stream));
+    c.mcols = ncols; c.niter = niter;
+    c.m_global = ncols; c.niter_global = niter;
+    c.zu_valid = false;
+    return c.sync();
+}
+
+extern "C" int glmmr_mcml_get_u(glmmr_mcml_ctx* h, double* u, int ldu)
+{
+    MCML_REQUIRE(h && u, "get_u: null argument");
+    Ctx& c = h->c;
+    MCML_REQUIRE(c.mcols > 0 && ldu >= c.Q, "get_u: no samples / bad ldu");
+    MCML_HIP(hipSetDevice(c.device));
+    return download_matrix(u, ldu, c.U.d(), c.U.ld, c.Q, c.mcols, c.stream);
+}
+
+extern "C" int glmmr_mcml_ctx_mvn_ll(glmmr_mcml_ctx* h, const double* theta, double* out)
+{
+    MCML_REQUIRE(h && theta && out, "mvn_ll: null argument");
+    Ctx& c = h->c;
+    MCML_HIP(hipSetDevice(c.device));
+    double s = 0;
+    MCML_TRY(mvn_loglik_sum(c, theta, &s));
+    double tot[2] = {s, (double)c.mcols};
+    MCML_TRY(allreduce_host(c, tot, 2));
+    *out = tot[0] / tot[1];        // loglV / ncols, mcmldmatrix.h:40
+    return MCML_OK;
+}
+
+extern "C" int glmmr_mcml_ctx_gen_D(glmmr_mcml_ctx* h, const double* theta, int chol, double* out, int ldo)
+{
+    MCML_REQUIRE(h && theta && out, "gen_D: null argument");
+    Ctx& c = h->c;
+    MCML_REQUIRE(ldo >= c.Q, "gen_D: ldo too small");
+    MCML_HIP(hipSetDevice(c.device));
+    MCML_TRY(mvn_gen_L(c, theta, chol != 0));
+    return download_matrix(out, ldo, c.L.d(), c.L.ld, c.Q, c.Q, c.stream);
+}
+
+// beta += (1/m sum X'W_iX)^-1 X' (1/m sum W_i detadmu resid_i); sigma = mean sigma_i
+// (mcmloptim.h:227-235); Gauss-Jordan with partial pivoting stands in for Eigen's .inverse()
+int mcml::mcnr_finish(int P, const double* stats, const double* beta, double* beta_out, double* sigma_out)
+{
+    const double m = stats[P * P + P + 1];
+    MCML_REQUIRE(m > 0, "mcnr: no samples");
+    std::vector<double> A(stats, stats + P * P), B((size_t)P * P, 0.0);
+    for (auto& v : A) v *= (double)1 / m;
+    for (int i = 0; i < P; i++) B[i + (size_t)i * P] = 1.0;
+    for (int c = 0; c < P; c++) {
+        int p = c; double best = fabs(A[c + (size_t)c * P]);
+        for (int i = c + 1; i < P; i++) if (fabs(A[i + (size_t)c * P]) > best) { best = fabs(A[i + (size_t)c * P]); p = i; }
+        if (best == 0.0 || best != best) { set_error("mcnr: X'WX is singular"); return MCML_ESINGULAR; }
+        if (p != c) for (int j = 0; j < P; j++) { std::swap(A[c + (size_t)j * P], A[p + (size_t)j * P]); std::swap(B[c + (size_t)j * P], B[p + (size_t)j * P]); }
+        double d = A[c + (size_t)c * P];
+        for (int j = 0; j < P; j++) { A[c + (size_t)j * P] /= d; B[c + (size_t)j * P] /= d; }
+        for (int i = 0; i < P; i++) if (i != c) {
+            double f = A[i + (size_t)c * P];
+            if (f != 0.0) for (int j = 0; j < P; j++) { A[i + (size_t)j * P] -= f * A[c + (size_t)j * P]; B[i + (size_t)j * P] -= f * B[c + (size_t)j * P]; }
+        }
+    }
+    for (int a = 0; a < P; a++) {
+        double inc = 0;
+        for (int b = 0; b < P; b++) inc += B[a + (size_t)b * P] * (stats[P * P + b] / m);
+        beta_out[a] = beta[a] + inc;
+    }
+    *sigma_out = stats[P * P + P] / m;
+    return MCML_OK;
+}
+
+extern "C" int glmmr_mcml_ctx_loglik(glmmr_mcml_ctx* h, const double* beta, double var_par, double* out)
+{
+    MCML_REQUIRE(h && beta && out, "loglik: null argument");
+    Ctx& c = h->c;
+    MCML_HIP(hipSetDevice(c.device));
+    MCML_TRY(model_update_beta(c, beta));
+    double s = 0;
+    MCML_TRY(model_loglik_sum(c, var_par, &s));
+    double tot[2] = {s, (double)c.niter};
+    MCML_TRY(allreduce_host(c, tot, 2));
+    *out = tot[0] / tot[1];        // ll.mean(), mcmlmodel.h:303
+    return MCML_OK;
+}
+
+extern "C" int glmmr_mcml_ctx_mcnr(glmmr_mcml_ctx* h, const double* beta, double var_par,
+                                   double* beta_out, double* sigma_out, double* stats_out)
+{
+    MCML_REQUIRE(h && beta && beta_out && sigma_out, "mcnr: null argument");
+    Ctx& c = h->c;
+    MCML_HIP(hipSetDevice(c.device));
+    MCML_TRY(model_update_beta(c, beta));
+    std::vector<double> st((size_t)c.P * c.P + c.P + 2);
+    MCML_TRY(model_mcnr_stats(c, var_par, st.data()));
+    if (stats_out) memcpy(stats_out, st.data(), sizeof(double) * ((size_t)c.P * c.P + c.P + 1));
+    return mcnr_finish(c.P, st.data(), beta, beta_out, sigma_out);
+}
+
+extern "C" int glmmr_mcml_ctx_update_L(glmmr_mcml_ctx* h, const double* theta)
+{
+    MCML_REQUIRE(h && theta, "update_L: null argument");
+    Ctx& c = h->c;
+    MCML_HIP(hipSetDevice(c.device));
+    MCML_TRY(mvn_gen_L(c, theta, true));
+    MCML_TRY(model_update_L(c));
+    return c.sync();
+}
+
+extern "C" int glmmr_mcml_ctx_set_L(glmmr_mcml_ctx* h, const double* L, int ldl)
+{
+    MCML_REQUIRE(h && L, "set_L: null argument");
+    Ctx& c = h->c;
+    MCML_REQUIRE(ldl >= c.Q, "set_L: ldl too small");
+    MCML_HIP(hipSetDevice(c.device));
+    MCML_TRY(upload_matrix(c.L, L, c.Q, c.Q, ldl, c.stream));
+    c.have_L = true;
+    MCML_TRY(model_update_L(c));
+    return c.sync();
+}
+
+extern "C" int glmmr_mcml_mvn_ll(const int32_t* cov, int cov_rows, const double* data, int data_len,
+                                 const double* eff_range, int eff_len, const double* gamma, int ngamma,
+                                 const double* u, int Q, int m, double* out)
+{
+    glmmr_mcml_problem p{};
+    p.cov = cov; p.cov_rows = cov_rows; p.data = data; p.data_len = data_len;
+    p.eff_range = eff_range; p.eff_len = eff_len; p.Q = Q;
+    glmmr_mcml_ctx* h = nullptr;
+    MCML_TRY(glmmr_mcml_ctx_create(&p, nullptr, &h));
+    int rc = MCML_OK;
+    if (ngamma < h->c.cov.npar) {
+        set_error("mvn_ll: %d covariance parameters given, the functions need %d", ngamma, h->c.cov.npar);
+        rc = MCML_EINVAL;
+    }
+    if (!rc) rc = glmmr_mcml_set_u(h, u, Q, m, m);
+    if (!rc) rc = glmmr_mcml_ctx_mvn_ll(h, gamma, out);
+    glmmr_mcml_ctx_destroy(h);
+    return rc;
+}

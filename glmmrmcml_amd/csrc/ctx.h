@@ -1,0 +1,98 @@
+// ctx.h -- the device-resident MCML problem: everything the hot path needs
+// stays in HBM between calls (Z, X, y, the samples u, L, ZL, workspaces); only
+// parameter vectors go down and scalars / small statistics come back.
+#pragma once
+#include "common.h"
+#include "covspec.h"
+
+namespace mcml {
+
+constexpr int CHOL_NB = 128;     // leaf size of the recursive Cholesky / TRSM
+constexpr int SMALL_BLOCK = 32;  // blocks up to this size are factorised one wave each
+
+// cross-rank reduction hook (sum, f64, in place on a device buffer).  Single
+// process: null.  bench.py / the distributed front end install a callback that
+// all-reduces the buffer with torch.distributed (backend "nccl" = RCCL).
+typedef int (*reduce_fn)(void* user, double* dev_buf, int n);
+
+struct HmcState {
+    int C = 0;                  // chains resident
+    DevMat V, R, UP, GRAD, GRADP;   // Q x C
+    DevMat MU, S;               // n x C
+    DevBuf chain;               // per-chain scalars, see hmc.hip
+    DevBuf partial;             // per-(row slot, chain) partial sums
+    int partial_slots = 0;
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // problem
+    int n = 0, Q = 0, P = 0, flink = 0, link_code = 0;
+    int z_width = 0;            // > 0: Z also held as padded-CSR rows of this width
+    DevBuf z_idx, z_val;        // n x z_width (column-major)
+    CovSpec cov;
+    DevMat Z, X;                // n x Q, n x P
+    DevBuf y;                   // n
+    DevBuf d_cov, d_data, d_blocks, d_rowblock;   // covariance spec on the device
+
+    // samples
+    DevMat U;                   // Q x mcols (u = L v)
+    int mcols = 0;              // columns held (theta-step uses all: mcmldmatrix.h:24)
+    int niter = 0;              // columns the beta-step uses (mcmlmodel.h:73,296)
+    int m_global = 0, niter_global = 0;   // across ranks (== local when single rank)
+    DevMat ZU;                  // n x mcols, cached Z u
+    bool zu_valid = false;
+
+    // model state
+    DevMat L, ZL, ZLT;          // Q x Q lower factor of D; n x Q; Q x n
+    DevBuf xb;                  // n
+    bool have_L = false;
+
+    // MVN workspaces
+    DevMat Dwork;               // maxdim x maxdim
+    DevMat Uwork;               // maxdim x mcols
+    DevBuf linv;                // (maxdim/128 + 1) x 128 x 128
+    DevBuf partials;            // reduction partials
+    DevBuf scalars;             // small device scalars: [0..15] results, [16] error flag (int)
+    int maxdim_large = 0;       // largest block that takes the recursive path
+    int n_small = 0, n_diag_rows = 0;
+
+    // sampler
+    HmcState hmc;
+
+    // distribution
+    int rank = 0, world = 1;
+    reduce_fn reduce = nullptr;
+    void* reduce_user = nullptr;
+    DevBuf reduce_buf;          // doubles handed to the reduce hook
+    DevBuf scratch;             // short-lived per-call scratch
+
+    int sync() { MCML_HIP(hipStreamSynchronize(stream)); return MCML_OK; }
+};
+
+// ---- mvn.hip ----
+int mvn_setup(Ctx& c);
+// sum over the locally held columns of sum_b log N(u_b; 0, D_b(theta)); *ncols = local columns
+int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out);
+// L = genD(0, chol=true, upper=false) (mcml_full.cpp:68): block-diagonal lower factor
+int mvn_gen_L(Ctx& c, const double* theta, bool chol);
+int potrf_lower(Ctx& c, double* A, int n, int lda);                          // in place
+int trsm_left_lower(Ctx& c, const double* L, int ldl, int n, double* U, int ldu, int m);
+
+// ---- model.hip ----
+int model_setup(Ctx& c, const double* Z, const double* X, const double* y);
+int allreduce_host(Ctx& c, double* vals, int n);
+int model_update_beta(Ctx& c, const double* beta);          // xb = X beta
+int model_update_zu(Ctx& c);                                // ZU = Z U (cached)
+int model_update_L(Ctx& c);                                 // ZL = Z L, ZLT
+int model_loglik_sum(Ctx& c, double var_par, double* sum_out);
+int model_mcnr_stats(Ctx& c, double var_par, double* stats /* P*P + P + 2 */);
+int mcnr_finish(int P, const double* stats, const double* beta, double* beta_out, double* sigma_out);
+
+// ---- reductions shared by several modules ----
+int device_sum(Ctx& c, const double* partials, int n, double* dev_out);
+
+}  // namespace mcml

@@ -1,0 +1,304 @@
+// model.hip -- mcmlModel on the device (mcmlmodel.h:28-307): xb = X beta, the
+// cached Z u, ZL = Z L, the Monte-Carlo log-likelihood (log_likelihood,
+// :284-304; functor L_likelihood, likelihood.h:48-65) and the sufficient
+// statistics of the MCNR step (mcmloptim.h:198-236).
+//
+// What the reference recomputes, this keeps: Z u is formed once per set of
+// samples (the reference redoes the n x Q x m GEMM on every objective
+// evaluation, mcmlmodel.h:286, and once per sample inside mcnr, :121); W stays
+// a diagonal (the reference materialises a dense n x n matrix, :62).
+// Z is held dense for the MFMA products and, when it is an indicator-like
+// matrix, also as padded-CSR rows so that Z u and Z L are row gathers.
+#include "ctx.h"
+#include "dgemm_mfma.h"
+#include "glm.h"
+#include "reduce.h"
+
+namespace mcml {
+
+// ------------------------------------------------------------------ reduce hook
+// sums `n` host doubles over all ranks (identity when single-process)
+int allreduce_host(Ctx& c, double* vals, int n)
+{
+    if (!c.reduce || c.world <= 1) return MCML_OK;
+    MCML_TRY(c.reduce_buf.ensure(sizeof(double) * (size_t)n));
+    MCML_HIP(hipMemcpyAsync(c.reduce_buf.p, vals, sizeof(double) * n, hipMemcpyHostToDevice, c.stream));
+    MCML_HIP(hipStreamSynchronize(c.stream));
+    int rc = c.reduce(c.reduce_user, c.reduce_buf.d(), n);
+    if (rc) { set_error("reduce hook failed (%d)", rc); return MCML_EINVAL; }
+    MCML_HIP(hipMemcpyAsync(vals, c.reduce_buf.p, sizeof(double) * n, hipMemcpyDeviceToHost, c.stream));
+    MCML_HIP(hipStreamSynchronize(c.stream));
+    return MCML_OK;
+}
+
+// ------------------------------------------------------------------ setup
+int model_setup(Ctx& c, const double* Z, const double* X, const double* y)
+{
+    const int n = c.n, Q = c.Q, P = c.P;
+    MCML_TRY(upload_matrix(c.Z, Z, n, Q, n, c.stream));
+    MCML_TRY(upload_matrix(c.X, X, n, P, n, c.stream));
+    MCML_TRY(c.y.ensure(sizeof(double) * (size_t)pad_ld(n)));
+    MCML_TRY(c.xb.ensure(sizeof(double) * (size_t)pad_ld(n)));
+    MCML_HIP(hipMemsetAsync(c.y.p, 0, sizeof(double) * (size_t)pad_ld(n), c.stream));
+    MCML_HIP(hipMemsetAsync(c.xb.p, 0, sizeof(double) * (size_t)pad_ld(n), c.stream));
+    std::vector<double> yy(y, y + n);
+    if (c.flink == 8)                      // mcmlmodel.h:90-92: y_ = y_.log()
+        for (auto& v : yy) v = log(v);
+    MCML_HIP(hipMemcpyAsync(c.y.p, yy.data(), sizeof(double) * n, hipMemcpyHostToDevice, c.stream));
+    // sparse rows of Z (indicator designs): padded CSR, width = max nnz per row
+    size_t nnz = 0; int maxrow = 0;
+    std::vector<int> cnt(n, 0);
+    for (int j = 0; j < Q; ++j)
+        for (int i = 0; i < n; ++i)
+            if (Z[i + (size_t)j * n] != 0.0) { ++cnt[i]; ++nnz; }
+    for (int i = 0; i < n; ++i) if (cnt[i] > maxrow) maxrow = cnt[i];
+    c.z_width = 0;
+    if (maxrow > 0 && maxrow <= 8 && (double)nnz <= 0.02 * (double)n * Q + 8.0 * n) {
+        c.z_width = maxrow;
+        std::vector<int> zi((size_t)n * maxrow, 0);
+        std::vector<double> zv((size_t)n * maxrow, 0.0);
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (int j = 0; j < Q; ++j)
+            for (int i = 0; i < n; ++i) {
+                double v = Z[i + (size_t)j * n];
+                if (v != 0.0) { int k = cnt[i]++; zi[i + (size_t)k * n] = j; zv[i + (size_t)k * n] = v; }
+            }
+        MCML_TRY(c.z_idx.ensure(sizeof(int) * zi.size()));
+        MCML_TRY(c.z_val.ensure(sizeof(double) * zv.size()));
+        MCML_HIP(hipMemcpyAsync(c.z_idx.p, zi.data(), sizeof(int) * zi.size(), hipMemcpyHostToDevice, c.stream));
+        MCML_HIP(hipMemcpyAsync(c.z_val.p, zv.data(), sizeof(double) * zv.size(), hipMemcpyHostToDevice, c.stream));
+        MCML_HIP(hipStreamSynchronize(c.stream));
+    }
+    MCML_HIP(hipStreamSynchronize(c.stream));
+    return MCML_OK;
+}
+
+// ------------------------------------------------------------------ xb = X beta
+__global__ void k_xb(const double* X, int ldx, int n, int P, const double* beta, double* xb)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0;
+    for (int p = 0; p < P; ++p) s += X[i + (size_t)p * ldx] * beta[p];   // Eigen: X * beta
+    xb[i] = s;
+}
+
+int model_update_beta(Ctx& c, const double* beta)
+{
+    MCML_REQUIRE(c.n > 0, "no model in this context");
+    MCML_TRY(c.scratch.ensure(sizeof(double) * 64));
+    MCML_REQUIRE(c.P <= 64, "P > 64 fixed effects");
+    MCML_HIP(hipMemcpyAsync(c.scratch.p, beta, sizeof(double) * c.P, hipMemcpyHostToDevice, c.stream));
+    hipLaunchKernelGGL(k_xb, dim3((c.n + 255) / 256), dim3(256), 0, c.stream, c.X.d(), c.X.ld, c.n, c.P,
+                       c.scratch.d(), c.xb.d());
+    MCML_HIP(hipGetLastError());
+    MCML_HIP(hipStreamSynchronize(c.stream));    // beta is a caller buffer
+    return MCML_OK;
+}
+
+// ------------------------------------------------------------------ Z * B (row gather or MFMA)
+// out[i, j] = sum_k zval[i,k] * B[zidx[i,k], j]
+__global__ __launch_bounds__(256) void k_zgather(const int* zidx, const double* zval, int width, int n,
+                                                 const double* B, int ldb, int ncols, double* out, int ldo)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int j = blockIdx.y; j < ncols; j += gridDim.y) {
+        double s = 0;
+        for (int k = 0; k < width; ++k) s += zval[i + (size_t)k * n] * B[zidx[i + (size_t)k * n] + (size_t)j * ldb];
+        out[i + (size_t)j * ldo] = s;
+    }
+}
+
+static int z_times(Ctx& c, const double* B, int ldb, int ncols, double* out, int ldo)
+{
+    if (c.z_width > 0) {
+        int gy = ncols < 1024 ? ncols : 1024;
+        hipLaunchKernelGGL(k_zgather, dim3((c.n + 255) / 256, gy), dim3(256), 0, c.stream, c.z_idx.as<int>(),
+                           c.z_val.d(), c.z_width, c.n, B, ldb, ncols, out, ldo);
+        MCML_HIP(hipGetLastError());
+        return MCML_OK;
+    }
+    EpiAxpby epi{out, ldo, 1.0, 0.0};
+    return launch_gemm<false>(c.stream, c.n, ncols, c.Q, c.Z.d(), c.Z.ld, B, ldb, epi);
+}
+
+// zu_ = Z * u (mcmlmodel.h:116-118), cached until the samples change
+int model_update_zu(Ctx& c)
+{
+    MCML_REQUIRE(c.n > 0 && c.mcols > 0, "update_zu: no model / samples");
+    if (c.zu_valid) return MCML_OK;
+    MCML_TRY(c.ZU.alloc(c.n, c.mcols));
+    MCML_TRY(z_times(c, c.U.d(), c.U.ld, c.mcols, c.ZU.d(), c.ZU.ld));
+    c.zu_valid = true;
+    return MCML_OK;
+}
+
+__global__ void k_transpose(const double* A, int lda, int rows, int cols, double* AT, int ldt)
+{
+    __shared__ double tile[32][33];
+    int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        int i = bx + tx, j = by + r;
+        tile[r][tx] = (i < rows && j < cols) ? A[i + (size_t)j * lda] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int j = by + tx, i = bx + r;
+        if (i < rows && j < cols) AT[j + (size_t)i * ldt] = tile[tx][r];
+    }
+}
+
+// ZL_ = Z * L (mcmlmodel.h:104-106) and its transpose (so that both HMC products
+// read their A operand M-contiguous)
+int model_update_L(Ctx& c)
+{
+    MCML_REQUIRE(c.n > 0 && c.have_L, "update_L: no model / L");
+    MCML_TRY(c.ZL.alloc(c.n, c.Q));
+    MCML_TRY(c.ZLT.alloc(c.Q, c.n));
+    if (c.z_width > 0) {
+        MCML_TRY(z_times(c, c.L.d(), c.L.ld, c.Q, c.ZL.d(), c.ZL.ld));
+    } else {
+        // L is lower triangular: N-major view of L^T is not needed; plain K-major product
+        EpiAxpby epi{c.ZL.d(), c.ZL.ld, 1.0, 0.0};
+        MCML_TRY(launch_gemm<false>(c.stream, c.n, c.Q, c.Q, c.Z.d(), c.Z.ld, c.L.d(), c.L.ld, epi));
+    }
+    hipLaunchKernelGGL(k_transpose, dim3((c.n + 31) / 32, (c.Q + 31) / 32), dim3(256), 0, c.stream, c.ZL.d(),
+                       c.ZL.ld, c.n, c.Q, c.ZLT.d(), c.ZLT.ld);
+    MCML_HIP(hipGetLastError());
+    return MCML_OK;
+}
+
+// ------------------------------------------------------------------ log_likelihood
+__global__ __launch_bounds__(256) void k_loglik(const double* ZU, int ldz, int n, int ncols, const double* xb,
+                                                const double* y, double var_par, int flink, double* partials)
+{
+    __shared__ double sh[4];
+    int i = blockIdx.x * 256 + threadIdx.x;
+    double acc = 0;
+    if (i < n) {
+        const double yi = y[i], xbi = xb[i];
+        for (int j = blockIdx.y; j < ncols; j += gridDim.y)
+            acc += glm_logpdf(yi, xbi + ZU[i + (size_t)j * ldz], var_par, flink);
+    }
+    double r = block_sum(acc, sh);
+    if (threadIdx.x == 0) partials[blockIdx.y * gridDim.x + blockIdx.x] = r;
+}
+
+// sum_{j < niter} sum_i logf(y_i | xb_i + (Z u)_ij) over the local columns
+int model_loglik_sum(Ctx& c, double var_par, double* sum_out)
+{
+    MCML_TRY(model_update_zu(c));
+    int gx = (c.n + 255) / 256, gy = c.niter < 64 ? c.niter : 64;
+    MCML_TRY(c.partials.ensure(sizeof(double) * (size_t)(gx * gy + 16)));
+    hipLaunchKernelGGL(k_loglik, dim3(gx, gy), dim3(256), 0, c.stream, c.ZU.d(), c.ZU.ld, c.n, c.niter,
+                       c.xb.d(), c.y.d(), var_par, c.flink, c.partials.d());
+    MCML_HIP(hipGetLastError());
+    MCML_TRY(device_sum(c, c.partials.d(), gx * gy, c.scalars.d() + 4));
+    MCML_HIP(hipMemcpyAsync(sum_out, c.scalars.d() + 4, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    MCML_HIP(hipStreamSynchronize(c.stream));
+    return MCML_OK;
+}
+
+// ------------------------------------------------------------------ MCNR statistics
+// one workgroup per sample column: sigma_i = sd(y - h^-1(xb + zd_i)) (mcmloptim.h:214-216)
+__global__ __launch_bounds__(256) void k_mcnr_col(const double* ZU, int ldz, int n, const double* xb,
+                                                  const double* y, int link_code, double* sig)
+{
+    __shared__ double sh[4];
+    __shared__ double mean_s;
+    const double* z = ZU + (size_t)blockIdx.x * ldz;
+    double acc = 0;
+    for (int j = threadIdx.x; j < n; j += 256) acc += y[j] - glm_mod_inv(xb[j] + z[j], link_code);
+    double r = block_sum(acc, sh);
+    if (threadIdx.x == 0) mean_s = r / n;
+    __syncthreads();
+    const double mean = mean_s;
+    acc = 0;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        double d = (y[j] - glm_mod_inv(xb[j] + z[j], link_code)) - mean;
+        acc += d * d;
+    }
+    r = block_sum(acc, sh);
+    if (threadIdx.x == 0) sig[blockIdx.x] = sqrt(r / (n - 1));
+}
+
+// one thread per observation: wsum_j = sum_i W_i,jj ; wusum_j = sum_i W_i,jj * detadmu * resid
+// (mcmlmodel.h:120-134, mcmloptim.h:213-225)
+__global__ __launch_bounds__(256) void k_mcnr_row(const double* ZU, int ldz, int n, int ncols, const double* xb,
+                                                  const double* y, int flink, int link_code, double nvar_par,
+                                                  double* wsum, double* wusum)
+{
+    int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const double yj = y[j], xbj = xb[j];
+    double a = 0, b = 0;
+    for (int i = 0; i < ncols; ++i) {
+        double eta = xbj + ZU[j + (size_t)i * ldz];
+        double w = 1 / (glm_dhdmu(eta, flink) * nvar_par);
+        double resid = yj - glm_mod_inv(eta, link_code);
+        a += w;
+        b += w * glm_detadmu(eta, link_code) * resid;
+    }
+    wsum[j] = a; wusum[j] = b;
+}
+
+// out[0 .. P*P) = X' diag(wsum) X ; out[P*P .. P*P+P) = X' wusum ; out[P*P+P] = sum sig ;
+// out[P*P+P+1] = number of sample columns summed
+__global__ __launch_bounds__(256) void k_mcnr_fin(const double* X, int ldx, int n, int P, const double* wsum,
+                                                  const double* wusum, const double* sig, int ncols, double* out)
+{
+    __shared__ double sh[4];
+    for (int o = 0; o < P * P + P + 1; ++o) {
+        double acc = 0;
+        if (o < P * P) {
+            int a = o % P, b = o / P;
+            for (int j = threadIdx.x; j < n; j += 256) acc += X[j + (size_t)a * ldx] * wsum[j] * X[j + (size_t)b * ldx];
+        } else if (o < P * P + P) {
+            int a = o - P * P;
+            for (int j = threadIdx.x; j < n; j += 256) acc += X[j + (size_t)a * ldx] * wusum[j];
+        } else {
+            for (int i = threadIdx.x; i < ncols; i += 256) acc += sig[i];
+        }
+        double r = block_sum(acc, sh);
+        if (threadIdx.x == 0) out[o] = r;
+    }
+    if (threadIdx.x == 0) out[P * P + P + 1] = (double)ncols;
+}
+
+// stats (host, P*P + P + 2 doubles): sum_i X'W_iX, sum_i X'(W_i detadmu resid_i), sum_i sigma_i
+// and the column count, summed over this rank's first `niter` columns and then over ranks:
+// the per-chain sufficient statistics of the MCNR step, one all-reduce.
+int model_mcnr_stats(Ctx& c, double var_par, double* stats)
+{
+    MCML_TRY(model_update_zu(c));
+    const int n = c.n, P = c.P, m = c.niter;
+    double nvar_par = 1.0;                       // mcmlmodel.h:123-130
+    if (c.flink == 7 || c.flink == 8) nvar_par *= var_par * var_par;
+    else if (c.flink >= 9 && c.flink <= 11) nvar_par *= var_par;
+    else if (c.flink == 12) nvar_par *= (1 + var_par);
+    const int ns = P * P + P + 2;
+    MCML_TRY(c.partials.ensure(sizeof(double) * (size_t)(2 * pad_ld(n) + m + ns + 16)));
+    double* wsum = c.partials.d();
+    double* wusum = wsum + pad_ld(n);
+    double* sig = wusum + pad_ld(n);
+    MCML_TRY(c.reduce_buf.ensure(sizeof(double) * (size_t)ns));
+    hipLaunchKernelGGL(k_mcnr_col, dim3(m), dim3(256), 0, c.stream, c.ZU.d(), c.ZU.ld, n, c.xb.d(), c.y.d(),
+                       c.link_code, sig);
+    hipLaunchKernelGGL(k_mcnr_row, dim3((n + 255) / 256), dim3(256), 0, c.stream, c.ZU.d(), c.ZU.ld, n, m,
+                       c.xb.d(), c.y.d(), c.flink, c.link_code, nvar_par, wsum, wusum);
+    hipLaunchKernelGGL(k_mcnr_fin, dim3(1), dim3(256), 0, c.stream, c.X.d(), c.X.ld, n, P, wsum, wusum, sig, m,
+                       c.reduce_buf.d());
+    MCML_HIP(hipGetLastError());
+    if (c.reduce && c.world > 1) {
+        MCML_HIP(hipStreamSynchronize(c.stream));
+        int rc = c.reduce(c.reduce_user, c.reduce_buf.d(), ns);   // RCCL all-reduce of the statistics
+        if (rc) { set_error("reduce hook failed (%d)", rc); return MCML_EINVAL; }
+    }
+    MCML_HIP(hipMemcpyAsync(stats, c.reduce_buf.p, sizeof(double) * ns, hipMemcpyDeviceToHost, c.stream));
+    MCML_HIP(hipStreamSynchronize(c.stream));
+    return MCML_OK;
+}
+
+}  // namespace mcml

@@ -1,0 +1,587 @@
+// mvn.hip -- multivariate-normal log-likelihood of the random effects,
+//   (1/m) sum_b sum_j log N(u_{b,j}; 0, D_b(theta)),
+// i.e. MCMLDmatrix::loglik / logdet / loglik_block (mcmldmatrix.h:23-78), the
+// D_likelihood functor (likelihood.h:31-46) and export mvn_ll
+// (mcml_optim.cpp:406-414), plus DMatrix::genD(0,chol,false) (mcml_full.cpp:68).
+//
+// The reference rebuilds and refactorises each block once per sample column
+// (defect D2); here every block is built and factorised once per theta:
+//   * all-gr blocks (diagonal, mcmldmatrix.h:61-65): closed form, one streaming pass
+//     over u (HBM-bound: 8 B per element);
+//   * blocks of dim <= 32: one wave builds + factorises the block in LDS and
+//     forward-substitutes 64 sample columns at a time;
+//   * larger blocks: fused covariance build -> recursive blocked Cholesky whose
+//     trailing updates are FP64-MFMA GEMMs (dgemm_mfma.h), 128-wide leaves
+//     factorised and inverted in LDS -> recursive TRSM of all m sample columns
+//     (MFMA GEMMs against the inverted leaves) -> Frobenius norm + log-det.
+// Reductions are two-stage with a fixed order, so the result is run-to-run
+// bit-reproducible.
+#include "ctx.h"
+#include "dgemm_mfma.h"
+#include "reduce.h"
+
+namespace mcml {
+
+#define LOG_2PI 1.8378770664093454835606594728112   /* log(2*M_PI), mcmldmatrix.h:63,75 */
+
+// ------------------------------------------------------------------ reductions
+// out[0] = (accumulate ? out[0] : 0) + scale * sum(partials[0..n))
+__global__ __launch_bounds__(256) void k_sum_partials(const double* partials, int n, double scale,
+                                                      double* out, int accumulate)
+{
+    __shared__ double sh[4];
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
+    double r = block_sum(v, sh);
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0) + scale * r;
+}
+
+int device_sum(Ctx& c, const double* partials, int n, double* dev_out)
+{
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, partials, n, 1.0, dev_out, 0);
+    MCML_HIP(hipGetLastError());
+    return MCML_OK;
+}
+
+// ------------------------------------------------------------------ diagonal blocks
+// dd[k] = prod_k theta^2 ("dmat(k,k)*dmat(k,k)"), dc[k] = -0.5 log(dd) - 0.5 log(2 pi)
+__global__ void k_diag_prep(int Q, const int* rowblock, const CovBlock* blocks, const int32_t* cov,
+                            int rows, ThetaArg th, double* dd, double* dc)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Q) return;
+    int b = rowblock[k];
+    if (b < 0) { dd[k] = 1.0; dc[k] = 0.0; return; }
+    CovBlock blk = blocks[b];
+    double val = 1.0;
+    for (int r = blk.r0; r < blk.r1; ++r) val = cov_term(1, 0.0, &th.v[cov[r + 4 * rows]], val);
+    double d = sqrt(val);           // the Cholesky factor of a diagonal block
+    dd[k] = d * d;
+    dc[k] = -0.5 * log(d * d) - 0.5 * LOG_2PI;
+}
+
+__global__ __launch_bounds__(256) void k_diag_ll(const double* U, int ldu, int Q, int mcols,
+                                                 const int* rowblock, const double* dd,
+                                                 const double* dc, double* partials)
+{
+    __shared__ double sh[4];
+    int k = blockIdx.x * 256 + threadIdx.x;
+    double acc = 0;
+    if (k < Q && rowblock[k] >= 0) {
+        const double idd = dd[k], c0 = dc[k];
+        for (int col = blockIdx.y; col < mcols; col += gridDim.y) {
+            double u = U[k + (size_t)col * ldu];
+            acc += c0 - 0.5 * u * u / idd;
+        }
+    }
+    double r = block_sum(acc, sh);
+    if (threadIdx.x == 0) partials[blockIdx.y * gridDim.x + blockIdx.x] = r;
+}
+
+// ------------------------------------------------------------------ covariance entry
+__device__ __forceinline__ double cov_entry(const CovBlock& blk, const int32_t* cov, int rows,
+                                            const double* bd, const ThetaArg& th, int i, int j)
+{
+    double val = 1.0;
+    int coff = 0;
+    for (int r = blk.r0; r < blk.r1; ++r) {
+        const int fn = cov[r + 2 * rows], nv = cov[r + 3 * rows], pi = cov[r + 4 * rows];
+        double d2 = 0.0;
+        for (int p = 0; p < nv; ++p) {
+            double df = bd[i + (size_t)(coff + p) * blk.dim] - bd[j + (size_t)(coff + p) * blk.dim];
+            d2 += df * df;
+        }
+        val = cov_term(fn, sqrt(d2), &th.v[pi], val);
+        coff += nv;
+    }
+    return val;
+}
+
+// ------------------------------------------------------------------ small blocks
+__global__ __launch_bounds__(64) void k_small_ll(const double* U, int ldu, int mcols,
+                                                 const int* small_ids, const CovBlock* blocks,
+                                                 const int32_t* cov, int rows, const double* data,
+                                                 ThetaArg th, double* partials, int* errflag)
+{
+    __shared__ double S[SMALL_BLOCK * (SMALL_BLOCK + 1)];
+    __shared__ double Zs[SMALL_BLOCK * 64];
+    const CovBlock blk = blocks[small_ids[blockIdx.x]];
+    const int dim = blk.dim, lane = threadIdx.x;
+    constexpr int LS = SMALL_BLOCK + 1;
+    const double* bd = data + blk.doff;
+    for (int e = lane; e < dim * dim; e += 64) {
+        int i = e % dim, j = e / dim;
+        if (i >= j) S[i * LS + j] = cov_entry(blk, cov, rows, bd, th, i, j);
+    }
+    __syncthreads();
+    // left-looking column Cholesky, same operation order as the CPU oracle
+    for (int j = 0; j < dim; ++j) {
+        if (lane == j) {
+            double d = S[j * LS + j];
+            for (int k = 0; k < j; ++k) d -= S[j * LS + k] * S[j * LS + k];
+            if (!(d > 0.0)) { atomicExch(errflag, 1); d = 1.0; }
+            S[j * LS + j] = sqrt(d);
+        }
+        __syncthreads();
+        if (lane > j && lane < dim) {
+            double s = S[lane * LS + j];
+            for (int k = 0; k < j; ++k) s -= S[lane * LS + k] * S[j * LS + k];
+            S[lane * LS + j] = s / S[j * LS + j];
+        }
+        __syncthreads();
+    }
+    double logdet = 0;
+    for (int i = 0; i < dim; ++i) logdet += 2 * log(S[i * LS + i]);
+    double acc = 0;
+    for (int col = blockIdx.y * 64 + lane; col < mcols; col += gridDim.y * 64) {
+        const double* u = U + blk.matstart + (size_t)col * ldu;
+        double quad = 0;
+        for (int i = 0; i < dim; ++i) {                      // algo::forward_sub, moremaths.h:166-179
+            double lsum = 0;
+            for (int j = 0; j < i; ++j) lsum += S[i * LS + j] * Zs[j * 64 + lane];
+            double z = (u[i] - lsum) / S[i * LS + i];
+            Zs[i * 64 + lane] = z;
+            quad += z * z;
+        }
+        acc += (-0.5 * dim * LOG_2PI - 0.5 * logdet - 0.5 * quad);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) partials[blockIdx.x * gridDim.y + blockIdx.y] = acc;
+}
+
+// ------------------------------------------------------------------ large blocks
+// lower triangle (mirrored) of one block's covariance matrix
+__global__ __launch_bounds__(256) void k_build_dense(double* A, int lda, int bidx, const CovBlock* blocks,
+                                                     const int32_t* cov, int rows, const double* data,
+                                                     ThetaArg th, int mirror)
+{
+    if (blockIdx.x < blockIdx.y) return;
+    const CovBlock blk = blocks[bidx];
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= blk.dim || j >= blk.dim || i < j) return;
+    double v = cov_entry(blk, cov, rows, data + blk.doff, th, i, j);
+    A[i + (size_t)j * lda] = v;
+    if (mirror && i != j) A[j + (size_t)i * lda] = v;
+}
+
+// Leaf of the recursive factorisation: n <= 128.  One workgroup keeps the
+// block in LDS (row stride 129: conflict-free column walks), factorises it in
+// 16-wide panels (the 16x16 diagonal tile in registers via wave shuffles), then
+// inverts the factor in place into the unused upper triangle.  Writes L over
+// the lower triangle of A and inv(L) to Linv (128 x 128, ld 128, upper zeroed).
+__global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, double* Linv, int* errflag)
+{
+    extern __shared__ __attribute__((aligned(16))) double S[];
+    constexpr int LS = 129;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < n * n; e += 256) {
+        int i = e % n, j = e / n;
+        S[i * LS + j] = (i >= j) ? A[i + (size_t)j * lda] : 0.0;
+    }
+    __syncthreads();
+    for (int kb = 0; kb < n; kb += 16) {
+        if (wave == 0) {
+            // (a) 16x16 diagonal tile, one row per lane (lanes >= 16 mirror lane&15)
+            const int r = lane & 15;
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                a[c] = (kb + r < n && kb + c < n) ? S[(kb + r) * LS + kb + c] : (r == c ? 1.0 : 0.0);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double diag = __shfl(a[c], c);
+                if (!(diag > 0.0)) { if (lane == 0) atomicExch(errflag, 1); diag = 1.0; }
+                double d = sqrt(diag);
+                double l = (r == c) ? d : a[c] / d;
+                a[c] = l;
+#pragma unroll
+                for (int j = c + 1; j < 16; ++j) {
+                    double lj = __shfl(l, j);
+                    if (r >= j) a[j] -= l * lj;
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (r >= c && kb + r < n && kb + c < n) S[(kb + r) * LS + kb + c] = a[c];
+            }
+        }
+        __syncthreads();
+        // (b) panel below the tile: x L11^T = a, one row per thread
+        for (int i = kb + 16 + tid; i < n; i += 256) {
+            double x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double s = S[i * LS + kb + c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) s -= x[k] * S[(kb + c) * LS + kb + k];
+                x[c] = s / S[(kb + c) * LS + kb + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) S[i * LS + kb + c] = x[c];
+        }
+        __syncthreads();
+        // (c) trailing update of the lower triangle
+        const int t0 = kb + 16, T = n - t0;
+        for (int e = tid; e < T * T; e += 256) {
+            int i = e / T, j = e - i * T;
+            if (j <= i) {
+                double s = 0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) s += S[(t0 + i) * LS + kb + c] * S[(t0 + j) * LS + kb + c];
+                S[(t0 + i) * LS + t0 + j] -= s;
+            }
+        }
+        __syncthreads();
+    }
+    // write L
+    for (int e = tid; e < n * n; e += 256) {
+        int i = e % n, j = e / n;
+        if (i >= j) A[i + (size_t)j * lda] = S[i * LS + j];
+    }
+    // inverse: X = inv(L); column j by thread j; X[i][j] (i > j) kept at S[j][i]
+    if (tid < n) {
+        const int j = tid;
+        const double xjj = 1.0 / S[j * LS + j];
+        for (int i = j + 1; i < n; ++i) {
+            double s = S[i * LS + j] * xjj;
+            for (int k = j + 1; k < i; ++k) s += S[i * LS + k] * S[j * LS + k];
+            S[j * LS + i] = -s / S[i * LS + i];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 128 * 128; e += 256) {
+        int i = e & 127, j = e >> 7;
+        double v = 0.0;
+        if (i < n && j < n) {
+            if (i == j) v = 1.0 / S[j * LS + j];
+            else if (i > j) v = S[j * LS + i];
+        }
+        Linv[i + j * 128] = v;
+    }
+}
+
+__global__ void k_copy_block(double* dst, int ldd, const double* src, int lds, int rows, int cols)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    for (int j = blockIdx.y; j < cols; j += gridDim.y) dst[i + (size_t)j * ldd] = src[i + (size_t)j * lds];
+}
+
+__global__ __launch_bounds__(256) void k_sumsq(const double* U, int ldu, int rows, int cols, double* partials)
+{
+    __shared__ double sh[4];
+    int i = blockIdx.x * 256 + threadIdx.x;
+    double acc = 0;
+    if (i < rows)
+        for (int j = blockIdx.y; j < cols; j += gridDim.y) {
+            double u = U[i + (size_t)j * ldu];
+            acc += u * u;
+        }
+    double r = block_sum(acc, sh);
+    if (threadIdx.x == 0) partials[blockIdx.y * gridDim.x + blockIdx.x] = r;
+}
+
+// scal[1] = logdet = sum 2 log L_ii (mcmldmatrix.h:67-70)
+__global__ __launch_bounds__(256) void k_logdet(const double* A, int lda, int n, double* out)
+{
+    __shared__ double sh[4];
+    double acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += 2 * log(A[i + (size_t)i * lda]);
+    double r = block_sum(acc, sh);
+    if (threadIdx.x == 0) out[0] = r;
+}
+
+// scal[0] += mcols*(-0.5 dim log 2pi - 0.5 logdet) - 0.5 sumsq   (mcmldmatrix.h:75)
+__global__ void k_finish_large(double* scal, int dim, int mcols)
+{
+    scal[0] += (double)mcols * (-0.5 * dim * LOG_2PI - 0.5 * scal[1]) - 0.5 * scal[2];
+}
+
+__global__ void k_zero_upper(double* A, int lda, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y;
+    if (i < n && j < n && i < j) A[i + (size_t)j * lda] = 0.0;
+}
+
+// ------------------------------------------------------------------ recursion (host)
+static inline int split128(int n)
+{
+    int h = (n / 2) / CHOL_NB * CHOL_NB;
+    return h < CHOL_NB ? CHOL_NB : h;
+}
+
+static int potrf_rec(Ctx& c, double* A0, int lda, int off, int n);
+static int trsm_right_rec(Ctx& c, const double* A0, int lda, int off, int n, double* X, int ldx, int M);
+
+// X (M x n) <- X * inv(L)^T, L = A0[off:off+n, off:off+n] lower
+static int trsm_right_rec(Ctx& c, const double* A0, int lda, int off, int n, double* X, int ldx, int M)
+{
+    if (n <= CHOL_NB) {
+        const double* Linv = c.linv.d() + (size_t)(off / CHOL_NB) * CHOL_NB * CHOL_NB;
+        EpiAxpby epi{X, ldx, 1.0, 0.0};
+        // in place: a workgroup reads its whole row band (K = n <= 128) before it writes
+        return launch_gemm<true>(c.stream, M, n, n, X, ldx, Linv, CHOL_NB, epi, false, 1);
+    }
+    const int n1 = split128(n), n2 = n - n1;
+    MCML_TRY(trsm_right_rec(c, A0, lda, off, n1, X, ldx, M));
+    const double* L21 = A0 + (off + n1) + (size_t)off * lda;
+    double* X2 = X + (size_t)n1 * ldx;
+    EpiAxpby epi{X2, ldx, -1.0, 1.0};
+    MCML_TRY(launch_gemm<true>(c.stream, M, n2, n1, X, ldx, L21, lda, epi));
+    return trsm_right_rec(c, A0, lda, off + n1, n2, X2, ldx, M);
+}
+
+static int potrf_rec(Ctx& c, double* A0, int lda, int off, int n)
+{
+    double* A = A0 + off + (size_t)off * lda;
+    if (n <= CHOL_NB) {
+        double* Linv = c.linv.d() + (size_t)(off / CHOL_NB) * CHOL_NB * CHOL_NB;
+        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), sizeof(double) * 128 * 129, c.stream,
+                           A, lda, n, Linv, c.scalars.as<int>() + 32);
+        MCML_HIP(hipGetLastError());
+        return MCML_OK;
+    }
+    const int n1 = split128(n), n2 = n - n1;
+    MCML_TRY(potrf_rec(c, A0, lda, off, n1));
+    double* A21 = A + n1;
+    MCML_TRY(trsm_right_rec(c, A0, lda, off, n1, A21, lda, n2));
+    double* A22 = A + n1 + (size_t)n1 * lda;
+    EpiAxpby epi{A22, lda, -1.0, 1.0};
+    MCML_TRY(launch_gemm<true>(c.stream, n2, n2, n1, A21, lda, A21, lda, epi, true));
+    return potrf_rec(c, A0, lda, off + n1, n2);
+}
+
+int potrf_lower(Ctx& c, double* A, int n, int lda)
+{
+    MCML_REQUIRE(n > 0 && lda >= n && (lda & 1) == 0, "potrf: bad shape n=%d lda=%d", n, lda);
+    MCML_TRY(c.linv.ensure(sizeof(double) * (size_t)(n / CHOL_NB + 1) * CHOL_NB * CHOL_NB));
+    static bool attr = false;
+    if (!attr) {
+        MCML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_leaf),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 128 * 129)));
+        attr = true;
+    }
+    return potrf_rec(c, A, lda, 0, n);
+}
+
+// U (n x m) <- inv(L) U, L = A0[off.., off..]; needs the leaf inverses potrf_lower left in c.linv
+static int trsm_left_rec(Ctx& c, const double* A0, int lda, int off, int n, double* U, int ldu, int m)
+{
+    if (n <= CHOL_NB) {
+        const double* Linv = c.linv.d() + (size_t)(off / CHOL_NB) * CHOL_NB * CHOL_NB;
+        EpiAxpby epi{U, ldu, 1.0, 0.0};
+        // in place: a workgroup reads its whole column band (K = n <= 128) before it writes
+        return launch_gemm<false>(c.stream, n, m, n, Linv, CHOL_NB, U, ldu, epi, false, 1);
+    }
+    const int n1 = split128(n), n2 = n - n1;
+    MCML_TRY(trsm_left_rec(c, A0, lda, off, n1, U, ldu, m));
+    const double* L21 = A0 + (off + n1) + (size_t)off * lda;
+    double* U2 = U + n1;
+    EpiAxpby epi{U2, ldu, -1.0, 1.0};
+    MCML_TRY(launch_gemm<false>(c.stream, n2, m, n1, L21, lda, U, ldu, epi));
+    return trsm_left_rec(c, A0, lda, off + n1, n2, U2, ldu, m);
+}
+
+int trsm_left_lower(Ctx& c, const double* L, int ldl, int n, double* U, int ldu, int m)
+{
+    return trsm_left_rec(c, L, ldl, 0, n, U, ldu, m);
+}
+
+// ------------------------------------------------------------------ setup
+int mvn_setup(Ctx& c)
+{
+    const CovSpec& cs = c.cov;
+    MCML_TRY(c.d_cov.ensure(sizeof(int32_t) * cs.cov.size()));
+    MCML_HIP(hipMemcpyAsync(c.d_cov.p, cs.cov.data(), sizeof(int32_t) * cs.cov.size(), hipMemcpyHostToDevice, c.stream));
+    MCML_TRY(c.d_data.ensure(sizeof(double) * (cs.data.size() + 1)));
+    if (!cs.data.empty())
+        MCML_HIP(hipMemcpyAsync(c.d_data.p, cs.data.data(), sizeof(double) * cs.data.size(), hipMemcpyHostToDevice, c.stream));
+    MCML_TRY(c.d_blocks.ensure(sizeof(CovBlock) * cs.blocks.size()));
+    MCML_HIP(hipMemcpyAsync(c.d_blocks.p, cs.blocks.data(), sizeof(CovBlock) * cs.blocks.size(), hipMemcpyHostToDevice, c.stream));
+    std::vector<int> rowblock(cs.N, -1);
+    c.maxdim_large = 0; c.n_small = 0; c.n_diag_rows = 0;
+    for (int b = 0; b < cs.B; ++b) {
+        const CovBlock& blk = cs.blocks[b];
+        if (blk.all_gr) {
+            for (int k = 0; k < blk.dim; ++k) rowblock[blk.matstart + k] = b;
+            c.n_diag_rows += blk.dim;
+        } else if (blk.dim <= SMALL_BLOCK) {
+            ++c.n_small;
+        } else if (blk.dim > c.maxdim_large) {
+            c.maxdim_large = blk.dim;
+        }
+    }
+    MCML_TRY(c.d_rowblock.ensure(sizeof(int) * (size_t)(cs.N + 1)));
+    MCML_HIP(hipMemcpyAsync(c.d_rowblock.p, rowblock.data(), sizeof(int) * cs.N, hipMemcpyHostToDevice, c.stream));
+    MCML_TRY(c.scalars.ensure(sizeof(double) * 64));
+    MCML_HIP(hipMemsetAsync(c.scalars.p, 0, sizeof(double) * 64, c.stream));
+    if (c.maxdim_large) {
+        MCML_TRY(c.Dwork.alloc(c.maxdim_large, c.maxdim_large));
+        MCML_HIP(hipMemsetAsync(c.Dwork.d(), 0, sizeof(double) * (size_t)c.Dwork.ld * c.maxdim_large, c.stream));
+        MCML_TRY(c.linv.ensure(sizeof(double) * (size_t)(c.maxdim_large / CHOL_NB + 1) * CHOL_NB * CHOL_NB));
+    }
+    MCML_HIP(hipStreamSynchronize(c.stream));
+    return MCML_OK;
+}
+
+static int theta_arg(const Ctx& c, const double* theta, ThetaArg& th)
+{
+    MCML_REQUIRE(theta, "theta is null");
+    memset(&th, 0, sizeof th);
+    for (int i = 0; i < c.cov.npar; ++i) th.v[i] = theta[i];
+    return MCML_OK;
+}
+
+static int check_errflag(Ctx& c, const char* what)
+{
+    int flag = 0;
+    MCML_HIP(hipMemcpyAsync(&flag, c.scalars.as<int>() + 32, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    MCML_HIP(hipStreamSynchronize(c.stream));
+    if (flag) {
+        MCML_HIP(hipMemsetAsync(c.scalars.as<int>() + 32, 0, sizeof(int), c.stream));
+        set_error("%s: covariance block is not positive definite", what);
+        return MCML_ENOTPD;
+    }
+    return MCML_OK;
+}
+
+// ------------------------------------------------------------------ loglik
+int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out)
+{
+    MCML_REQUIRE(c.mcols > 0 && c.U.d(), "mvn_ll: no samples set");
+    ThetaArg th;
+    MCML_TRY(theta_arg(c, theta, th));
+    const CovSpec& cs = c.cov;
+    const int Q = cs.N, m = c.mcols;
+    double* scal = c.scalars.d();
+    const int32_t* dcov = c.d_cov.as<int32_t>();
+    const CovBlock* dblk = c.d_blocks.as<CovBlock>();
+    const int* drb = c.d_rowblock.as<int>();
+    MCML_HIP(hipMemsetAsync(scal, 0, sizeof(double) * 4, c.stream));
+
+    if (c.n_diag_rows > 0) {
+        MCML_TRY(c.partials.ensure(sizeof(double) * (size_t)(2 * Q + 65536)));
+        double* dd = c.partials.d();
+        double* dc = dd + Q;
+        double* part = dc + Q;
+        hipLaunchKernelGGL(k_diag_prep, dim3((Q + 255) / 256), dim3(256), 0, c.stream, Q, drb, dblk, dcov,
+                           cs.rows, th, dd, dc);
+        dim3 grid((Q + 255) / 256, 1);
+        int gy = 65536 / (int)grid.x; if (gy > m) gy = m; if (gy > 64) gy = 64; if (gy < 1) gy = 1;
+        grid.y = gy;
+        hipLaunchKernelGGL(k_diag_ll, grid, dim3(256), 0, c.stream, c.U.d(), c.U.ld, Q, m, drb, dd, dc, part);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, part, (int)(grid.x * grid.y), 1.0, scal, 1);
+        MCML_HIP(hipGetLastError());
+    }
+    if (c.n_small > 0) {
+        std::vector<int> ids;
+        for (int b = 0; b < cs.B; ++b)
+            if (!cs.blocks[b].all_gr && cs.blocks[b].dim <= SMALL_BLOCK) ids.push_back(b);
+        int ny = (m + 63) / 64; if (ny > 16) ny = 16;
+        // ids + partials live in one buffer: [ids | partials]
+        size_t idbytes = round_up_sz(sizeof(int) * ids.size(), 16);
+        DevBuf& wb = c.scratch;      // scratch that outlives the launch
+        MCML_TRY(wb.ensure(idbytes + sizeof(double) * ids.size() * ny + 1024));
+        MCML_HIP(hipMemcpyAsync(wb.p, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, c.stream));
+        double* part = reinterpret_cast<double*>(static_cast<char*>(wb.p) + idbytes);
+        hipLaunchKernelGGL(k_small_ll, dim3((unsigned)ids.size(), ny), dim3(64), 0, c.stream, c.U.d(), c.U.ld, m,
+                           wb.as<int>(), dblk, dcov, cs.rows, c.d_data.d(), th, part, c.scalars.as<int>() + 32);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, part, (int)ids.size() * ny, 1.0, scal, 1);
+        MCML_HIP(hipGetLastError());
+        MCML_HIP(hipStreamSynchronize(c.stream));   // ids is a host temporary
+    }
+    if (c.maxdim_large > 0) {
+        MCML_TRY(c.Uwork.alloc(c.maxdim_large, m));
+        for (int b = 0; b < cs.B; ++b) {
+            const CovBlock& blk = cs.blocks[b];
+            if (blk.all_gr || blk.dim <= SMALL_BLOCK) continue;
+            const int d = blk.dim;
+            dim3 g((d + 15) / 16, (d + 15) / 16);
+            hipLaunchKernelGGL(k_build_dense, g, dim3(256), 0, c.stream, c.Dwork.d(), c.Dwork.ld, b, dblk, dcov,
+                               cs.rows, c.d_data.d(), th, 0);
+            MCML_HIP(hipGetLastError());
+            MCML_TRY(potrf_lower(c, c.Dwork.d(), d, c.Dwork.ld));
+            int gy = m < 256 ? m : 256;
+            hipLaunchKernelGGL(k_copy_block, dim3((d + 255) / 256, gy), dim3(256), 0, c.stream, c.Uwork.d(),
+                               c.Uwork.ld, c.U.d() + blk.matstart, c.U.ld, d, m);
+            MCML_HIP(hipGetLastError());
+            MCML_TRY(trsm_left_lower(c, c.Dwork.d(), c.Dwork.ld, d, c.Uwork.d(), c.Uwork.ld, m));
+            int gx = (d + 255) / 256; gy = m < 64 ? m : 64;
+            MCML_TRY(c.partials.ensure(sizeof(double) * (size_t)(gx * gy + 16)));
+            hipLaunchKernelGGL(k_sumsq, dim3(gx, gy), dim3(256), 0, c.stream, c.Uwork.d(), c.Uwork.ld, d, m, c.partials.d());
+            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, c.partials.d(), gx * gy, 1.0, scal + 2, 0);
+            hipLaunchKernelGGL(k_logdet, dim3(1), dim3(256), 0, c.stream, c.Dwork.d(), c.Dwork.ld, d, scal + 1);
+            hipLaunchKernelGGL(k_finish_large, dim3(1), dim3(1), 0, c.stream, scal, d, m);
+            MCML_HIP(hipGetLastError());
+        }
+    }
+    MCML_HIP(hipMemcpyAsync(sum_out, scal, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    MCML_TRY(check_errflag(c, "mvn_ll"));
+    return MCML_OK;
+}
+
+// ------------------------------------------------------------------ genD
+__global__ void k_diag_fill(double* L, int ldl, int Q, const int* rowblock, const CovBlock* blocks,
+                            const int32_t* cov, int rows, ThetaArg th, int chol)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Q) return;
+    int b = rowblock[k];
+    if (b < 0) return;
+    CovBlock blk = blocks[b];
+    double val = 1.0;
+    for (int r = blk.r0; r < blk.r1; ++r) val = cov_term(1, 0.0, &th.v[cov[r + 4 * rows]], val);
+    L[k + (size_t)k * ldl] = chol ? sqrt(val) : val;
+}
+
+int mvn_gen_L(Ctx& c, const double* theta, bool chol)
+{
+    ThetaArg th;
+    MCML_TRY(theta_arg(c, theta, th));
+    const CovSpec& cs = c.cov;
+    const int Q = cs.N;
+    MCML_TRY(c.L.alloc(Q, Q));
+    MCML_HIP(hipMemsetAsync(c.L.d(), 0, sizeof(double) * (size_t)c.L.ld * Q, c.stream));
+    const int32_t* dcov = c.d_cov.as<int32_t>();
+    const CovBlock* dblk = c.d_blocks.as<CovBlock>();
+    if (c.n_diag_rows > 0)
+        hipLaunchKernelGGL(k_diag_fill, dim3((Q + 255) / 256), dim3(256), 0, c.stream, c.L.d(), c.L.ld, Q,
+                           c.d_rowblock.as<int>(), dblk, dcov, cs.rows, th, chol ? 1 : 0);
+    for (int b = 0; b < cs.B; ++b) {
+        const CovBlock& blk = cs.blocks[b];
+        if (blk.all_gr) continue;
+        const int d = blk.dim;
+        double* A = c.L.at(blk.matstart, blk.matstart);
+        dim3 g((d + 15) / 16, (d + 15) / 16);
+        hipLaunchKernelGGL(k_build_dense, g, dim3(256), 0, c.stream, A, c.L.ld, b, dblk, dcov, cs.rows,
+                           c.d_data.d(), th, chol ? 0 : 1);
+        MCML_HIP(hipGetLastError());
+        if (chol) {
+            // blocks start at arbitrary (possibly odd) offsets: factorise in the
+            // aligned workspace when the view is not 16-byte aligned
+            if (d <= CHOL_NB || (blk.matstart & 1) == 0) {
+                MCML_TRY(potrf_lower(c, A, d, c.L.ld));
+            } else {
+                DevMat tmp;
+                MCML_TRY(tmp.alloc(d, d));
+                hipLaunchKernelGGL(k_copy_block, dim3((d + 255) / 256, d < 256 ? d : 256), dim3(256), 0, c.stream,
+                                   tmp.d(), tmp.ld, A, c.L.ld, d, d);
+                MCML_TRY(potrf_lower(c, tmp.d(), d, tmp.ld));
+                hipLaunchKernelGGL(k_copy_block, dim3((d + 255) / 256, d < 256 ? d : 256), dim3(256), 0, c.stream,
+                                   A, c.L.ld, tmp.d(), tmp.ld, d, d);
+                MCML_HIP(hipStreamSynchronize(c.stream));
+            }
+            // the SYRK updates of diagonal tiles also touch their upper halves
+            if (d > CHOL_NB)
+                hipLaunchKernelGGL(k_zero_upper, dim3((d + 255) / 256, d), dim3(256), 0, c.stream, A, c.L.ld, d);
+        }
+    }
+    MCML_HIP(hipGetLastError());
+    MCML_TRY(check_errflag(c, "genD"));
+    c.have_L = chol;
+    return MCML_OK;
+}
+
+}  // namespace mcml

@@ -6,7 +6,8 @@
  *
  * Conventions: every function returns 0 or a negative error code and never
  * throws or calls the R API; glmmr_mcml_last_error() gives the text.  The
- * caller owns every buffer it passes.  There is no CPU fallback: without a
+ * caller owns every buffer it passes; a context owns its device memory and is
+ * used from one host thread at a time.  There is no CPU fallback: without a
  * visible gfx950 device compute entry points return GLMMR_MCML_ENODEVICE.
  */
 #ifndef GLMMR_MCML_C_H
@@ -29,6 +30,78 @@ extern "C" {
 /* text of the calling thread's last error; replaces Rcpp's BEGIN_RCPP/END_RCPP
  * exception -> R condition translation (src/RcppExports.cpp:18,43) */
 const char* glmmr_mcml_last_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* Device-resident problem                                                    */
+/* ------------------------------------------------------------------------- */
+
+/* The arguments every Rcpp export receives (R6ModelExtMCML.R:399-419):
+ * covariance$get_D_data() = (cov, data), eff_range, Z, X, y, family, link.
+ * Z, X, y may be NULL (n = 0) for a context that only evaluates mvn_ll. */
+typedef struct glmmr_mcml_problem {
+    const int32_t* cov;       /* cov_rows x 5 column-major (mcml_optim.cpp:20-21) */
+    int            cov_rows;
+    const double*  data;      /* flattened block data (mcml_optim.cpp:22) */
+    int            data_len;
+    const double*  eff_range; /* per-function effective range (mcml_optim.cpp:23) */
+    int            eff_len;
+    const double*  Z;         /* n x Q */
+    const double*  X;         /* n x P */
+    const double*  y;         /* n */
+    int            n, Q, P;
+    const char*    family;    /* "poisson" | "binomial" | "gaussian" | "gamma" | "beta" */
+    const char*    link;
+} glmmr_mcml_problem;
+
+/* reduction hook: sum `n` doubles at `dev_buf` (device memory) over all ranks,
+ * in place.  NULL = single process. */
+typedef int (*glmmr_mcml_reduce_fn)(void* user, double* dev_buf, int n);
+
+typedef struct glmmr_mcml_dev_opts {
+    int   device;          /* HIP device ordinal */
+    void* stream;          /* hipStream_t to run on, or NULL for a private stream */
+    int   rank, world;     /* this process's shard of the chains / sample columns */
+    glmmr_mcml_reduce_fn reduce;
+    void* reduce_user;
+} glmmr_mcml_dev_opts;
+
+typedef struct glmmr_mcml_ctx glmmr_mcml_ctx;
+
+int glmmr_mcml_ctx_create(const glmmr_mcml_problem* prob, const glmmr_mcml_dev_opts* opts,
+                          glmmr_mcml_ctx** out);
+int glmmr_mcml_ctx_destroy(glmmr_mcml_ctx* ctx);
+
+/* samples u (Q x ncols, this rank's columns).  niter = columns the beta-step
+ * reads (mcmlmodel.h:73,296); the theta-step reads all ncols (mcmldmatrix.h:24). */
+int glmmr_mcml_set_u(glmmr_mcml_ctx* ctx, const double* u, int Q, int ncols, int niter);
+int glmmr_mcml_get_u(glmmr_mcml_ctx* ctx, double* u, int ldu);
+
+/* MCMLDmatrix::loglik(u) at theta (mcmldmatrix.h:23-41) */
+int glmmr_mcml_ctx_mvn_ll(glmmr_mcml_ctx* ctx, const double* theta, double* out);
+/* DMatrix::genD(0, chol, false) (mcml_full.cpp:68) -> out (Q x Q) */
+int glmmr_mcml_ctx_gen_D(glmmr_mcml_ctx* ctx, const double* theta, int chol, double* out, int ldo);
+
+/* mcmlModel::log_likelihood() at beta / var_par (mcmlmodel.h:284-304; L_likelihood,
+ * likelihood.h:57-64 returns its negative) */
+int glmmr_mcml_ctx_loglik(glmmr_mcml_ctx* ctx, const double* beta, double var_par, double* out);
+/* one mcmloptim::mcnr() step (mcmloptim.h:198-236).  stats_out (nullable):
+ * P*P + P + 1 doubles = sum_i X'W_iX | sum_i X'(W_i detadmu resid_i) | sum_i sigma_i */
+int glmmr_mcml_ctx_mcnr(glmmr_mcml_ctx* ctx, const double* beta, double var_par, double* beta_out,
+                        double* sigma_out, double* stats_out);
+/* dmat.update_parameters(theta); L = genD(0,true,false); model.update_L()
+ * (mcml_full.cpp:120-125) */
+int glmmr_mcml_ctx_update_L(glmmr_mcml_ctx* ctx, const double* theta);
+/* take L as given (export mcmc_sample receives it, mcml_full.cpp:315) */
+int glmmr_mcml_ctx_set_L(glmmr_mcml_ctx* ctx, const double* L, int ldl);
+
+/* ------------------------------------------------------------------------- */
+/* Mirrors of the Rcpp exports (host buffers in, host buffers out)            */
+/* ------------------------------------------------------------------------- */
+
+/* mvn_ll(cov, data, eff_range, gamma, u)  -- src/mcml_optim.cpp:406-414 */
+int glmmr_mcml_mvn_ll(const int32_t* cov, int cov_rows, const double* data, int data_len,
+                      const double* eff_range, int eff_len, const double* gamma, int ngamma,
+                      const double* u, int Q, int m, double* out);
 
 /* ---- test hooks (building blocks exposed for tests/ and bench.py only) ---- */
 int glmmr_mcml_dbg_dgemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb,

@@ -173,7 +173,7 @@ class Context:
         d = HmcDiag()
         ii = None if inj_init is None else _f(inj_init)
         im = None if inj_mom is None else _f(inj_mom)
-        total = warmup + nsamp
+        total = warmup + (nsamp if chains == 1 else -(-nsamp // chains))   # proposals per chain
         flags = np.zeros((chains, total), dtype=np.uint8, order="F") if want_trace else None
         probs = np.zeros((chains, total), order="F") if want_trace else None
         ncols = C.c_int()

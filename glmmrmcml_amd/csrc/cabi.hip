@@ -6,6 +6,12 @@ using namespace mcml;
 
 struct glmmr_mcml_ctx { Ctx c; };
 
+namespace mcml {
+int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_opts* o, uint64_t seed,
+               uint32_t iter_idx, const double* inj_init, const double* inj_mom, uint8_t* flags_out,
+               double* probs_out, glmmr_mcml_hmc_diag* diag, int* ncols_out);
+}
+
 static int flink_of(const char* family, const char* link)
 {
     // mcmlmodel.h:74-87 string_to_case
@@ -222,6 +228,25 @@ extern "C" int glmmr_mcml_ctx_set_L(glmmr_mcml_ctx* h, const double* L, int ldl)
     c.have_L = true;
     MCML_TRY(model_update_L(c));
     return c.sync();
+}
+
+extern "C" int glmmr_mcml_ctx_hmc_sample(glmmr_mcml_ctx* h, const double* beta, double var_par,
+                                         const glmmr_mcml_hmc_opts* opts, uint64_t seed, uint32_t iter_idx,
+                                         const double* inj_init, const double* inj_mom, uint8_t* flags_out,
+                                         double* probs_out, glmmr_mcml_hmc_diag* diag, int* ncols_out)
+{
+    MCML_REQUIRE(h && beta && opts, "hmc_sample: null argument");
+    MCML_HIP(hipSetDevice(h->c.device));
+    return hmc_sample(h->c, beta, var_par, opts, seed, iter_idx, inj_init, inj_mom, flags_out, probs_out,
+                      diag, ncols_out);
+}
+
+extern "C" int glmmr_mcml_dbg_log_prob_grad(glmmr_mcml_ctx* h, const double* beta, double var_par,
+                                            const double* V, int ncols, double* lp, double* G)
+{
+    MCML_REQUIRE(h && beta && V && lp && G && ncols > 0, "log_prob_grad: bad argument");
+    MCML_HIP(hipSetDevice(h->c.device));
+    return hmc_dbg_log_prob_grad(h->c, beta, var_par, V, ncols, lp, G);
 }
 
 extern "C" int glmmr_mcml_mvn_ll(const int32_t* cov, int cov_rows, const double* data, int data_len,

@@ -92,6 +92,11 @@ int model_loglik_sum(Ctx& c, double var_par, double* sum_out);
 int model_mcnr_stats(Ctx& c, double var_par, double* stats /* P*P + P + 2 */);
 int mcnr_finish(int P, const double* stats, const double* beta, double* beta_out, double* sigma_out);
 
+// ---- hmc.hip ----
+struct glmmr_mcml_hmc_opts_fwd;
+int hmc_dbg_log_prob_grad(Ctx& c, const double* beta, double var_par, const double* V, int ncols, double* lp,
+                          double* G);
+
 // ---- reductions shared by several modules ----
 int device_sum(Ctx& c, const double* partials, int n, double* dev_out);
 

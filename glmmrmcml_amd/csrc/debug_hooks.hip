@@ -72,3 +72,37 @@ extern "C" int glmmr_mcml_dbg_dgemm_bench(int M, int N, int K, int b_nmajor, int
 }
 
 extern "C" const char* glmmr_mcml_last_error(void) { return mcml::last_error(); }
+
+// ---- RNG contract on the device (bitwise twins of oracle/mcml_oracle.c) ----
+#include "rng.h"
+__global__ void k_dbg_normals(uint64_t seed, uint32_t chain, uint32_t prop, uint32_t tag, int n, double* out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rng_normal(seed, (uint32_t)i, chain, prop, tag);
+}
+__global__ void k_dbg_minstd(uint32_t seed, int n, double* out)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t x = seed % 2147483647u;
+    if (x == 0) x = 1;
+    for (int i = 0; i < n; ++i) out[i] = minstd_canonical(x);
+}
+extern "C" int glmmr_mcml_dbg_normals(uint64_t seed, uint32_t chain, uint32_t prop, uint32_t tag, int n,
+                                      double* out)
+{
+    DevBuf b;
+    MCML_TRY(b.ensure(sizeof(double) * (size_t)n));
+    hipLaunchKernelGGL(k_dbg_normals, dim3((n + 255) / 256), dim3(256), 0, nullptr, seed, chain, prop, tag, n, b.d());
+    MCML_HIP(hipGetLastError());
+    MCML_HIP(hipMemcpy(out, b.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    return MCML_OK;
+}
+extern "C" int glmmr_mcml_dbg_minstd(uint32_t seed, int n, double* out)
+{
+    DevBuf b;
+    MCML_TRY(b.ensure(sizeof(double) * (size_t)n));
+    hipLaunchKernelGGL(k_dbg_minstd, dim3(1), dim3(64), 0, nullptr, seed, n, b.d());
+    MCML_HIP(hipGetLastError());
+    MCML_HIP(hipMemcpy(out, b.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    return MCML_OK;
+}

@@ -1,0 +1,421 @@
+// hmc.hip -- the random-effects HMC sampler, mcmcRunHMC (mhmcmc.h:16-160), run as
+// C independent chains at once.
+//
+// The reference runs ONE chain whose every leapfrog step is two n x Q GEMVs that
+// stream ZL (200 MB at n = Q = 5000) and are strictly sequential.  Here the
+// chains are the columns of Q x C state matrices, so one leapfrog step of all
+// chains is two FP64-MFMA GEMMs that read ZL once:
+//     forward   MU = xb + ZL * UP ,  S = s(y, MU)          (n x Q x C)
+//     backward  g  = -UP + post * ZL' * S                   (Q x n x C)
+// with the score and the leapfrog update fused into the GEMM epilogues.  Each
+// chain keeps its own step size / dual-averaging state (mhmcmc.h:107-116), its
+// own minstd accept stream (:27,55,85) and its own number of steps; chains that
+// have finished their trajectory are masked in the backward epilogue.
+// log_prob(u) and log_grad(u) of the current state are cached from the step that
+// produced it instead of being recomputed (the reference recomputes them,
+// :64,82): same numbers, 2*steps GEMMs per proposal instead of 2*steps + 4.
+#include "../../include/glmmr_mcml_c.h"
+#include "ctx.h"
+#include "dgemm_mfma.h"
+#include "glm.h"
+#include "reduce.h"
+#include "rng.h"
+
+namespace mcml {
+
+struct ChainArrays {
+    double *e, *ebar, *H, *lpcur, *K0;
+    int *steps, *acc;
+    uint32_t* gen;
+    long long* leap;
+};
+
+static ChainArrays chain_arrays(const HmcState& h)
+{
+    ChainArrays a;
+    const size_t C = (size_t)round_up(h.C, 16);
+    double* d = h.chain.d();
+    a.e = d; a.ebar = d + C; a.H = d + 2 * C; a.lpcur = d + 3 * C; a.K0 = d + 4 * C;
+    a.leap = reinterpret_cast<long long*>(d + 5 * C);
+    a.steps = reinterpret_cast<int*>(d + 6 * C);
+    a.acc = a.steps + C;
+    a.gen = reinterpret_cast<uint32_t*>(a.acc + C);
+    return a;
+}
+
+// ------------------------------------------------------------------ GEMM epilogues
+// forward: MU = xb + acc ; S = score(y, MU)          (mcmlmodel.h:160-162,169-276)
+struct EpiForward {
+    double* MU; double* S; int ld; const double* xb; const double* y; int flink;
+    template <int TM, int TN>
+    __device__ __forceinline__ void operator()(d4 (&acc)[TM][TN], int mB, int nB, int lane, int M, int N,
+                                               int) const {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = mB + 16 * i + (lane & 15);
+            if (m >= M) continue;
+            const double xbi = xb[m], yi = y[m];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nB + 16 * j + (lane >> 4) + 4 * r;
+                    if (n < N) {
+                        const double mu = xbi + acc[i][j][r];
+                        MU[m + (size_t)n * ld] = mu;
+                        S[m + (size_t)n * ld] = glm_score(yi, mu, flink);
+                    }
+                }
+        }
+    }
+};
+
+// backward: g = -x + post*acc.  mode 0: GRAD = g (initial state).
+// mode 1 (leapfrog step s): for chains with s < steps: GRADP = g; R += e/2 g;
+// and, unless it was the chain's last step, R += e/2 g; UP += e R   (mhmcmc.h:73-78)
+struct EpiBackward {
+    const double* Xs; double* G; double* R; double* UP; int ld;
+    const double* e; const int* steps; int s; double post; int mode;
+    template <int TM, int TN>
+    __device__ __forceinline__ void operator()(d4 (&acc)[TM][TN], int mB, int nB, int lane, int M, int N,
+                                               int) const {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nB + 16 * j + (lane >> 4) + 4 * r;
+                if (n >= N) continue;
+                int st = 0; double en = 0.0;
+                if (mode == 1) { st = steps[n]; en = e[n]; if (s >= st) continue; }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int m = mB + 16 * i + (lane & 15);
+                    if (m >= M) continue;
+                    const size_t off = m + (size_t)n * ld;
+                    const double x = Xs[off];
+                    double g = -1.0 * x;
+                    g = g + post * acc[i][j][r];
+                    G[off] = g;
+                    if (mode == 1) {
+                        double rr = R[off];
+                        rr = rr + (en / 2) * g;
+                        if (s + 1 < st) {
+                            rr = rr + (en / 2) * g;
+                            UP[off] = x + en * rr;
+                        }
+                        R[off] = rr;
+                    }
+                }
+            }
+    }
+};
+
+// ------------------------------------------------------------------ per-chain kernels
+__global__ __launch_bounds__(256) void k_hmc_init(double* V, int ld, int Q, ChainArrays ca, uint64_t seed,
+                                                  uint32_t chain_offset, uint32_t iter_idx, const double* inj_init)
+{
+    const int c = blockIdx.x;
+    const uint32_t gid = chain_offset + (uint32_t)c;
+    for (int q = threadIdx.x; q < Q; q += 256)
+        V[q + (size_t)c * ld] = inj_init ? inj_init[q + (size_t)c * Q]
+                                         : rng_normal(seed, (uint32_t)q, gid, 0u, 16u * iter_idx + 0u);
+    if (threadIdx.x == 0) {                                   // initialise_u, mhmcmc.h:47-59
+        ca.e[c] = 0.001; ca.ebar[c] = 1.0; ca.H[c] = 0.0; ca.acc[c] = 0; ca.leap[c] = 0;
+        ca.gen[c] = chain_minstd_seed(seed, gid, iter_idx);
+        ca.steps[c] = 1;
+    }
+}
+
+// log_prob of column c: sum_i logf(y_i | MU_ic) + sum_k logN(x_k; 0, 1)   (mcmlmodel.h:138-153)
+__device__ __forceinline__ double chain_log_prob(const double* MU, int ldm, int n, const double* X, int ldx,
+                                                 int Q, const double* y, double var_par, int flink, int c,
+                                                 double* sh)
+{
+    double ll = 0, lp = 0;
+    for (int i = threadIdx.x; i < n; i += 256) ll += glm_logpdf(y[i], MU[i + (size_t)c * ldm], var_par, flink);
+    for (int k = threadIdx.x; k < Q; k += 256) lp += glm_logpdf(X[k + (size_t)c * ldx], 0, 1, 7);
+    double a = block_sum(ll, sh);
+    double b = block_sum(lp, sh);
+    return a + b;    // valid in thread 0
+}
+
+__global__ __launch_bounds__(256) void k_hmc_lp0(const double* MU, int ldm, int n, const double* V, int ld, int Q,
+                                                 const double* y, double var_par, int flink, double* lpcur)
+{
+    __shared__ double sh[4];
+    double v = chain_log_prob(MU, ldm, n, V, ld, Q, y, var_par, flink, blockIdx.x, sh);
+    if (threadIdx.x == 0) lpcur[blockIdx.x] = v;
+}
+
+// new_proposal, first part (mhmcmc.h:62-75): momentum, K0, steps, first half step + position
+__global__ __launch_bounds__(256) void k_hmc_propose(const double* V, const double* GRAD, double* R, double* UP,
+                                                     int ld, int Q, ChainArrays ca, double lambda, int max_steps,
+                                                     uint64_t seed, uint32_t chain_offset, uint32_t iter_idx,
+                                                     int it, const double* inj_mom, int C)
+{
+    __shared__ double sh[4];
+    const int c = blockIdx.x;
+    const uint32_t gid = chain_offset + (uint32_t)c;
+    const double e = ca.e[c];
+    double ss = 0;
+    for (int q = threadIdx.x; q < Q; q += 256) {
+        const size_t off = q + (size_t)c * ld;
+        double r = inj_mom ? inj_mom[q + ((size_t)it * C + c) * Q]
+                           : rng_normal(seed, (uint32_t)q, gid, (uint32_t)it, 16u * iter_idx + 2u);
+        ss += r * r;
+        const double g = GRAD[off], v = V[off];
+        r = r + (e / 2) * g;
+        R[off] = r;
+        UP[off] = v + e * r;
+    }
+    double tot = block_sum(ss, sh);
+    if (threadIdx.x == 0) {
+        ca.K0[c] = 0.5 * tot;
+        double st = round(lambda / e);                       // mhmcmc.h:69-70
+        if (!(st >= 1.0)) st = 1.0;
+        if (st > (double)max_steps) st = (double)max_steps;
+        ca.steps[c] = (int)st;
+        ca.leap[c] += (long long)st;
+    }
+}
+
+__global__ void k_max_steps(const int* steps, int C, int* out)
+{
+    __shared__ int sh[256];
+    int v = 0;
+    for (int i = threadIdx.x; i < C; i += 256) v = max(v, steps[i]);
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] = max(sh[threadIdx.x], sh[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// new_proposal, second part (mhmcmc.h:80-117)
+__global__ __launch_bounds__(256) void k_hmc_accept(double* V, double* GRAD, const double* R, const double* UP,
+                                                    const double* GRADP, int ld, int Q, const double* MU, int ldm,
+                                                    int n, const double* y, double var_par, int flink,
+                                                    ChainArrays ca, double target_accept, int adapt, int it,
+                                                    int C, uint8_t* flags, double* probs)
+{
+    __shared__ double sh[4];
+    __shared__ int acc_s;
+    const int c = blockIdx.x;
+    double l2 = chain_log_prob(MU, ldm, n, UP, ld, Q, y, var_par, flink, c, sh);
+    double kin = 0;
+    for (int k = threadIdx.x; k < Q; k += 256) { double r = R[k + (size_t)c * ld]; kin += r * r; }
+    kin = block_sum(kin, sh);
+    if (threadIdx.x == 0) {
+        const double lprt = 0.5 * kin, lpr = ca.K0[c], l1 = ca.lpcur[c];
+        const double prob = fmin(1.0, exp(-l1 + lpr + l2 - lprt));
+        uint32_t g = ca.gen[c];
+        const double runif = minstd_canonical(g);
+        ca.gen[c] = g;
+        const int acc = runif < prob;
+        acc_s = acc;
+        if (acc) { ca.lpcur[c] = l2; ca.acc[c] += 1; }
+        if (flags) flags[c + (size_t)it * C] = (uint8_t)acc;
+        if (probs) probs[c + (size_t)it * C] = prob;
+        if (adapt) {                                         // mhmcmc.h:107-114
+            const int iter = it + 1;
+            const double f1 = 1.0 / (iter + 10);
+            const double H = (1 - f1) * ca.H[c] + f1 * (target_accept - prob);
+            ca.H[c] = H;
+            const double loge = -4.60517 - (sqrt((double)iter / 0.05)) * H;
+            const double powm = pow((double)iter, -0.75);
+            const double logbare = powm * loge + (1 - powm) * log(ca.ebar[c]);
+            ca.e[c] = exp(loge);
+            ca.ebar[c] = exp(logbare);
+        } else {
+            ca.e[c] = ca.ebar[c];                            // :116
+        }
+    }
+    __syncthreads();
+    const int acc = acc_s;
+    if (acc)
+        for (int k = threadIdx.x; k < Q; k += 256) {
+            const size_t off = k + (size_t)c * ld;
+            V[off] = UP[off];
+            GRAD[off] = GRADP[off];
+        }
+}
+
+// store the current state of every chain as sample columns c*stride + col
+__global__ __launch_bounds__(256) void k_hmc_store(const double* V, int ld, int Q, double* SAMP, int lds,
+                                                   int stride, int col)
+{
+    const int c = blockIdx.x;
+    for (int k = threadIdx.x; k < Q; k += 256) SAMP[k + (size_t)(c * stride + col) * lds] = V[k + (size_t)c * ld];
+}
+
+__global__ void k_hmc_diag(ChainArrays ca, int C, double* out)
+{
+    // out: [0] sum accept, [1] sum e, [2] min e, [3] max e, [4] max steps, [5] sum leapfrog
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double sa = 0, se = 0, mn = 1e300, mx = 0, ms = 0, sl = 0;
+    for (int c = 0; c < C; ++c) {
+        sa += ca.acc[c]; se += ca.e[c];
+        mn = fmin(mn, ca.e[c]); mx = fmax(mx, ca.e[c]);
+        ms = fmax(ms, (double)ca.steps[c]); sl += (double)ca.leap[c];
+    }
+    out[0] = sa; out[1] = se; out[2] = mn; out[3] = mx; out[4] = ms; out[5] = sl;
+}
+
+// ------------------------------------------------------------------ host
+static int hmc_alloc(Ctx& c, int C)
+{
+    HmcState& h = c.hmc;
+    h.C = C;
+    MCML_TRY(h.V.alloc(c.Q, C)); MCML_TRY(h.R.alloc(c.Q, C)); MCML_TRY(h.UP.alloc(c.Q, C));
+    MCML_TRY(h.GRAD.alloc(c.Q, C)); MCML_TRY(h.GRADP.alloc(c.Q, C));
+    MCML_TRY(h.MU.alloc(c.n, C)); MCML_TRY(h.S.alloc(c.n, C));
+    MCML_TRY(h.chain.ensure(sizeof(double) * (size_t)round_up(C, 16) * 8));
+    // padding rows of the operands the GEMMs read must hold finite values
+    MCML_HIP(hipMemsetAsync(h.V.d(), 0, sizeof(double) * (size_t)h.V.ld * C, c.stream));
+    MCML_HIP(hipMemsetAsync(h.UP.d(), 0, sizeof(double) * (size_t)h.UP.ld * C, c.stream));
+    MCML_HIP(hipMemsetAsync(h.S.d(), 0, sizeof(double) * (size_t)h.S.ld * C, c.stream));
+    return MCML_OK;
+}
+
+// MU = xb + ZL * X ; S = score
+static int hmc_forward(Ctx& c, const double* X, int ldx)
+{
+    HmcState& h = c.hmc;
+    EpiForward epi{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink};
+    return launch_gemm<false>(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
+}
+
+static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_par, int mode)
+{
+    HmcState& h = c.hmc;
+    ChainArrays ca = chain_arrays(h);
+    EpiBackward epi{Xs, G, h.R.d(), h.UP.d(), h.V.ld, ca.e, ca.steps, s, glm_score_post(var_par, c.flink), mode};
+    return launch_gemm<false>(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
+}
+
+// log_prob and log_grad of every column of the current V
+static int hmc_eval_state(Ctx& c, double var_par)
+{
+    HmcState& h = c.hmc;
+    ChainArrays ca = chain_arrays(h);
+    MCML_TRY(hmc_forward(c, h.V.d(), h.V.ld));
+    hipLaunchKernelGGL(k_hmc_lp0, dim3(h.C), dim3(256), 0, c.stream, h.MU.d(), h.MU.ld, c.n, h.V.d(), h.V.ld, c.Q,
+                       c.y.d(), var_par, c.flink, ca.lpcur);
+    MCML_HIP(hipGetLastError());
+    return hmc_backward(c, h.V.d(), h.GRAD.d(), 0, var_par, 0);
+}
+
+int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_opts* o, uint64_t seed,
+               uint32_t iter_idx, const double* inj_init, const double* inj_mom, uint8_t* flags_out,
+               double* probs_out, glmmr_mcml_hmc_diag* diag, int* ncols_out)
+{
+    MCML_REQUIRE(c.n > 0 && c.have_L && c.ZL.d(), "hmc: model / L not set (call update_L or set_L first)");
+    MCML_REQUIRE(o && o->warmup >= 0 && o->nsamp > 0 && o->max_steps >= 1 && o->lambda > 0,
+                 "hmc: bad options");
+    MCML_REQUIRE(beta, "hmc: beta is null");
+    const int C = o->chains > 0 ? o->chains : 1;
+    const int d = (C == 1) ? o->nsamp : (o->nsamp + C - 1) / C;   // draws per chain
+    const int total = o->warmup + d;
+    const int ncols = (C == 1) ? d + 1 : C * d;                   // mhmcmc.h:126: Q x (nsamp+1)
+    const int Q = c.Q, n = c.n;
+    HmcState& h = c.hmc;
+    MCML_TRY(model_update_beta(c, beta));
+    MCML_TRY(hmc_alloc(c, C));
+    ChainArrays ca = chain_arrays(h);
+    DevMat samp;
+    MCML_TRY(samp.alloc(Q, ncols));
+    MCML_HIP(hipMemsetAsync(samp.d(), 0, sizeof(double) * (size_t)samp.ld * ncols, c.stream));
+
+    DevBuf d_init, d_mom, d_flags, d_probs;
+    const double* p_init = nullptr; const double* p_mom = nullptr;
+    if (inj_init) {
+        MCML_TRY(d_init.ensure(sizeof(double) * (size_t)Q * C));
+        MCML_HIP(hipMemcpyAsync(d_init.p, inj_init, sizeof(double) * (size_t)Q * C, hipMemcpyHostToDevice, c.stream));
+        p_init = d_init.d();
+    }
+    if (inj_mom) {
+        MCML_TRY(d_mom.ensure(sizeof(double) * (size_t)Q * C * total));
+        MCML_HIP(hipMemcpyAsync(d_mom.p, inj_mom, sizeof(double) * (size_t)Q * C * total, hipMemcpyHostToDevice, c.stream));
+        p_mom = d_mom.d();
+    }
+    if (flags_out) MCML_TRY(d_flags.ensure((size_t)C * total));
+    if (probs_out) MCML_TRY(d_probs.ensure(sizeof(double) * (size_t)C * total));
+
+    hipLaunchKernelGGL(k_hmc_init, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.V.ld, Q, ca, seed,
+                       (uint32_t)o->chain_offset, iter_idx, p_init);
+    MCML_HIP(hipGetLastError());
+    MCML_TRY(hmc_eval_state(c, var_par));
+    if (C == 1 && o->warmup == 0)
+        hipLaunchKernelGGL(k_hmc_store, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.V.ld, Q, samp.d(), samp.ld, 0, 0);
+
+    int* d_maxs = c.scalars.as<int>() + 34;
+    for (int it = 0; it < total; ++it) {
+        hipLaunchKernelGGL(k_hmc_propose, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(), h.UP.d(),
+                           h.V.ld, Q, ca, o->lambda, o->max_steps, seed, (uint32_t)o->chain_offset, iter_idx, it,
+                           p_mom, C);
+        hipLaunchKernelGGL(k_max_steps, dim3(1), dim3(256), 0, c.stream, ca.steps, C, d_maxs);
+        MCML_HIP(hipGetLastError());
+        int maxs = 0;
+        MCML_HIP(hipMemcpyAsync(&maxs, d_maxs, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+        MCML_HIP(hipStreamSynchronize(c.stream));
+        MCML_REQUIRE(maxs >= 1 && maxs <= o->max_steps, "hmc: step count %d out of range", maxs);
+        for (int s = 0; s < maxs; ++s) {
+            MCML_TRY(hmc_forward(c, h.UP.d(), h.UP.ld));
+            MCML_TRY(hmc_backward(c, h.UP.d(), h.GRADP.d(), s, var_par, 1));
+        }
+        const int adapt = (it < o->warmup) && (it < o->adapt);     // mhmcmc.h:131-136
+        hipLaunchKernelGGL(k_hmc_accept, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(), h.UP.d(),
+                           h.GRADP.d(), h.V.ld, Q, h.MU.d(), h.MU.ld, n, c.y.d(), var_par, c.flink, ca,
+                           o->target_accept, adapt, it, C, flags_out ? d_flags.as<uint8_t>() : nullptr,
+                           probs_out ? d_probs.d() : nullptr);
+        int col = -1, stride = 0;
+        if (C == 1) {
+            if (it == o->warmup - 1) col = 0;                      // samples.col(0) = u_, :142
+            else if (it >= o->warmup) col = it - o->warmup + 1;    // samples.col(i+1) = u_, :147
+        } else if (it >= o->warmup) { col = it - o->warmup; stride = d; }
+        if (col >= 0)
+            hipLaunchKernelGGL(k_hmc_store, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.V.ld, Q, samp.d(), samp.ld,
+                               stride, col);
+        MCML_HIP(hipGetLastError());
+    }
+    // return (L * samples)  (mhmcmc.h:155)
+    MCML_TRY(c.U.alloc(Q, ncols));
+    MCML_HIP(hipMemsetAsync(c.U.d(), 0, sizeof(double) * (size_t)c.U.ld * ncols, c.stream));
+    {
+        EpiAxpby epi{c.U.d(), c.U.ld, 1.0, 0.0};
+        MCML_TRY(launch_gemm<false>(c.stream, Q, ncols, Q, c.L.d(), c.L.ld, samp.d(), samp.ld, epi));
+    }
+    c.mcols = ncols;
+    c.niter = (C == 1) ? d : ncols;                                // mcmlmodel.h:73 vs mhmcmc.h:126 (D5)
+    c.zu_valid = false;
+    if (flags_out) MCML_HIP(hipMemcpyAsync(flags_out, d_flags.p, (size_t)C * total, hipMemcpyDeviceToHost, c.stream));
+    if (probs_out) MCML_HIP(hipMemcpyAsync(probs_out, d_probs.p, sizeof(double) * (size_t)C * total, hipMemcpyDeviceToHost, c.stream));
+    double dg[6] = {0, 0, 0, 0, 0, 0};
+    hipLaunchKernelGGL(k_hmc_diag, dim3(1), dim3(64), 0, c.stream, ca, C, c.scalars.d() + 8);
+    MCML_HIP(hipMemcpyAsync(dg, c.scalars.d() + 8, sizeof dg, hipMemcpyDeviceToHost, c.stream));
+    MCML_HIP(hipStreamSynchronize(c.stream));
+    if (diag) {
+        diag->accept_rate = dg[0] / ((double)C * total);
+        diag->mean_e = dg[1] / C; diag->min_e = dg[2]; diag->max_e = dg[3];
+        diag->max_steps_used = (int)dg[4]; diag->leapfrog_total = (long long)dg[5];
+    }
+    if (ncols_out) *ncols_out = ncols;
+    return MCML_OK;
+}
+
+// test hook: log_prob (A4) and log_grad (A5) of every column of V
+int hmc_dbg_log_prob_grad(Ctx& c, const double* beta, double var_par, const double* V, int ncols, double* lp,
+                          double* G)
+{
+    MCML_REQUIRE(c.n > 0 && c.have_L && c.ZL.d(), "log_prob_grad: model / L not set");
+    MCML_TRY(model_update_beta(c, beta));
+    MCML_TRY(hmc_alloc(c, ncols));
+    HmcState& h = c.hmc;
+    MCML_HIP(hipMemcpy2DAsync(h.V.d(), sizeof(double) * h.V.ld, V, sizeof(double) * c.Q, sizeof(double) * c.Q,
+                              ncols, hipMemcpyHostToDevice, c.stream));
+    MCML_TRY(hmc_eval_state(c, var_par));
+    ChainArrays ca = chain_arrays(h);
+    MCML_HIP(hipMemcpyAsync(lp, ca.lpcur, sizeof(double) * ncols, hipMemcpyDeviceToHost, c.stream));
+    return download_matrix(G, c.Q, h.GRAD.d(), h.GRAD.ld, c.Q, ncols, c.stream);
+}
+
+}  // namespace mcml

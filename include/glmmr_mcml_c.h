@@ -94,6 +94,34 @@ int glmmr_mcml_ctx_update_L(glmmr_mcml_ctx* ctx, const double* theta);
 /* take L as given (export mcmc_sample receives it, mcml_full.cpp:315) */
 int glmmr_mcml_ctx_set_L(glmmr_mcml_ctx* ctx, const double* L, int ldl);
 
+/* mcmcRunHMC options (mhmcmc.h:37-43; R field mcmc_options, R6ModelExtMCML.R:867-872) */
+typedef struct glmmr_mcml_hmc_opts {
+    int    warmup;
+    int    nsamp;          /* samples wanted in total (m) */
+    int    adapt;          /* proposals that adapt the step size; reference: 100 (mhmcmc.h:123) */
+    double lambda;         /* trajectory length */
+    int    max_steps;
+    double target_accept;
+    int    chains;         /* 1: the reference's one sequential chain, u is Q x (nsamp+1);
+                              C > 1: C chains x ceil(nsamp/C) post-warmup draws, u is Q x C*ceil(nsamp/C) */
+    int    chain_offset;   /* global id of this rank's first chain (keys the RNG streams) */
+} glmmr_mcml_hmc_opts;
+
+typedef struct glmmr_mcml_hmc_diag {
+    double    accept_rate, mean_e, min_e, max_e;
+    int       max_steps_used;
+    long long leapfrog_total;
+} glmmr_mcml_hmc_diag;
+
+/* mcmcRunHMC::sample (mhmcmc.h:121-157): fills the context's samples with L * v.
+ * inj_init (Q x chains) / inj_mom (Q x chains x proposals) replace the generated
+ * initial state / momenta (parity tests); flags_out / probs_out (chains x proposals)
+ * receive every accept decision and acceptance probability.  All four nullable. */
+int glmmr_mcml_ctx_hmc_sample(glmmr_mcml_ctx* ctx, const double* beta, double var_par,
+                              const glmmr_mcml_hmc_opts* opts, uint64_t seed, uint32_t iter_idx,
+                              const double* inj_init, const double* inj_mom, uint8_t* flags_out,
+                              double* probs_out, glmmr_mcml_hmc_diag* diag, int* ncols_out);
+
 /* ------------------------------------------------------------------------- */
 /* Mirrors of the Rcpp exports (host buffers in, host buffers out)            */
 /* ------------------------------------------------------------------------- */
@@ -107,6 +135,12 @@ int glmmr_mcml_mvn_ll(const int32_t* cov, int cov_rows, const double* data, int 
 int glmmr_mcml_dbg_dgemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb,
                          int b_nmajor, double alpha, double beta, double* C, int ldc,
                          int lower_only, int force_tile /* -1 = auto */);
+/* mcmlModel::log_prob / log_grad (mcmlmodel.h:138-279) of every column of V (Q x ncols) */
+int glmmr_mcml_dbg_log_prob_grad(glmmr_mcml_ctx* ctx, const double* beta, double var_par, const double* V,
+                                 int ncols, double* lp, double* G);
+/* RNG contract on the device: Philox/AS241 normals and the minstd canonical stream */
+int glmmr_mcml_dbg_normals(uint64_t seed, uint32_t chain, uint32_t prop, uint32_t tag, int n, double* out);
+int glmmr_mcml_dbg_minstd(uint32_t seed, int n, double* out);
 int glmmr_mcml_dbg_dgemm_bench(int M, int N, int K, int b_nmajor, int iters, int force_tile,
                                double* ms_per_launch);
 

@@ -556,7 +556,7 @@ int orc_mvn_ll(const int32_t *cov, int rows, const double *data, const double *e
             if (rc) rc_all = rc;
         }
         if (!rc_all) {
-#pragma omp parallel
+#pragma omp parallel if ((long long)dim * dim * (per_column_refactor ? dim : 1) * m > 2000000)
             {
                 double *work = (double *)malloc(sizeof(double) * (size_t)dim);
                 double *Lp = per_column_refactor
@@ -598,7 +598,7 @@ int orc_mvn_ll(const int32_t *cov, int rows, const double *data, const double *e
  * whatever the thread count. */
 void orc_gemv_n(int n, int Q, const double *A, const double *v, double *out)
 {
-#pragma omp parallel
+#pragma omp parallel if ((long long)n * Q > 200000)
     {
         int nt = 1, t = 0;
 #ifdef _OPENMP
@@ -616,7 +616,7 @@ void orc_gemv_n(int n, int Q, const double *A, const double *v, double *out)
 /* out = A' s */
 void orc_gemv_t(int n, int Q, const double *A, const double *s, double *out)
 {
-#pragma omp parallel for
+#pragma omp parallel for if ((long long)n * Q > 200000)
     for (int j = 0; j < Q; j++) {
         const double *a = A + (size_t)j * n;
         double acc = 0;
@@ -628,7 +628,7 @@ void orc_gemv_t(int n, int Q, const double *A, const double *s, double *out)
 void orc_gemm_nn(int M, int N, int K, const double *A, int lda, const double *B, int ldb,
                  double *C, int ldc)
 {
-#pragma omp parallel for
+#pragma omp parallel for if ((long long)M * N * K > 2000000)
     for (int j = 0; j < N; j++) {
         double *c = C + (size_t)j * ldc;
         for (int i = 0; i < M; i++) c[i] = 0;
@@ -713,7 +713,7 @@ double orc_model_loglik(int n, int Q, int m, const double *Z, const double *xb,
         zu = zd;
     }
     double *ll = (double *)calloc((size_t)m, sizeof(double));
-#pragma omp parallel for
+#pragma omp parallel for if ((long long)n * m > 200000)
     for (int j = 0; j < m; j++) {
         double acc = 0;
         for (int i = 0; i < n; i++)

@@ -13,6 +13,17 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
+# OpenMP must not oversubscribe the CPUs this process may actually use (a GPU box
+# exposes many hardware threads but grants a small share): bound the team and
+# make idle threads sleep instead of spin.  Set before libgomp initialises.
+try:
+    _NCPU = len(os.sched_getaffinity(0))
+except AttributeError:                      # pragma: no cover
+    _NCPU = os.cpu_count() or 1
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(_NCPU, 16))))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("OMP_DYNAMIC", "false")
+
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)
 c_u8p = C.POINTER(C.c_uint8)
@@ -79,6 +90,10 @@ def lib():
         L.orc_gemm_nn.argtypes = [C.c_int, C.c_int, C.c_int, c_dp, C.c_int, c_dp, C.c_int, c_dp, C.c_int]
         _LIB = L
     return _LIB
+
+
+def num_threads():
+    return lib().orc_num_threads()
 
 
 def _d(a):

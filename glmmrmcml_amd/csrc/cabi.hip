@@ -1,6 +1,7 @@
 // cabi.hip -- the extern "C" boundary (include/glmmr_mcml_c.h).
 #include "../../include/glmmr_mcml_c.h"
 #include "ctx.h"
+#include <random>
 
 using namespace mcml;
 
@@ -69,8 +70,15 @@ extern "C" int glmmr_mcml_ctx_create(const glmmr_mcml_problem* p, const glmmr_mc
     c.world = (o && o->world > 0) ? o->world : 1;
     c.reduce = o ? (reduce_fn)o->reduce : nullptr;
     c.reduce_user = o ? o->reduce_user : nullptr;
-    int rc = c.cov.parse(p->cov, p->cov_rows, p->data, p->data_len, p->eff_range, p->eff_len);
-    if (rc) return fail(rc);
+    int rc = MCML_OK;
+    if (p->cov) {
+        rc = c.cov.parse(p->cov, p->cov_rows, p->data, p->data_len, p->eff_range, p->eff_len);
+        if (rc) return fail(rc);
+    } else {
+        // no covariance description (export mcmc_sample receives L itself, mcml_full.cpp:315)
+        if (p->Q <= 0) { set_error("ctx_create: neither cov nor Q given"); return fail(MCML_EINVAL); }
+        c.cov.N = p->Q;
+    }
     c.Q = c.cov.N;
     if (p->Q > 0 && p->Q != c.cov.N) {
         set_error("Z has %d columns but the covariance blocks sum to %d", p->Q, c.cov.N);
@@ -267,4 +275,217 @@ extern "C" int glmmr_mcml_mvn_ll(const int32_t* cov, int cov_rows, const double*
     if (!rc) rc = glmmr_mcml_ctx_mvn_ll(h, gamma, out);
     glmmr_mcml_ctx_destroy(h);
     return rc;
+}
+
+// ------------------------------------------------------------------------- drivers
+namespace mcml {
+int drv_optim(Ctx& c, const double* start, int nstart, int trace, int mcnr, const glmmr_mcml_ext* e,
+              double* beta, double* theta, double* sigma);
+int drv_simlik(Ctx& c, const double* start, int nstart, int trace, const glmmr_mcml_ext* e, double* beta,
+               double* theta, double* sigma);
+int drv_hess(Ctx& c, const double* start, int nstart, double tol, int trace, double* H);
+int drv_aic(Ctx& c, const double* beta_par, int nbeta, const double* cov_par, int ncov, double* out);
+int drv_full(Ctx& c, const double* start, int nstart, int mcnr, int m, int maxiter, int warmup, double tol,
+             int verbose, double lambda, int trace, int refresh, int maxsteps, double target_accept,
+             const glmmr_mcml_ext* e, double* beta_out, double* theta_out, double* sigma_out,
+             int* converged_out, int* iters_out, glmmr_mcml_hmc_diag* last_diag);
+}
+
+extern "C" int glmmr_mcml_sample_cols(int m, int chains)
+{
+    if (m <= 0) return 0;
+    if (chains <= 1) return m + 1;                 // mhmcmc.h:126
+    return chains * ((m + chains - 1) / chains);
+}
+
+extern "C" int glmmr_mcml_ctx_ncols(glmmr_mcml_ctx* h) { return h ? h->c.mcols : 0; }
+extern "C" int glmmr_mcml_ctx_npar(glmmr_mcml_ctx* h) { return h ? h->c.cov.npar : 0; }
+
+extern "C" int glmmr_mcml_ctx_optim(glmmr_mcml_ctx* h, const double* start, int nstart, int trace, int mcnr,
+                                    const glmmr_mcml_ext* ext, double* beta, double* theta, double* sigma)
+{
+    MCML_REQUIRE(h && start && beta && theta && sigma, "optim: null argument");
+    MCML_REQUIRE(h->c.n > 0, "optim: context has no model");
+    MCML_HIP(hipSetDevice(h->c.device));
+    return drv_optim(h->c, start, nstart, trace, mcnr, ext, beta, theta, sigma);
+}
+
+extern "C" int glmmr_mcml_ctx_simlik(glmmr_mcml_ctx* h, const double* start, int nstart, int trace,
+                                     const glmmr_mcml_ext* ext, double* beta, double* theta, double* sigma)
+{
+    MCML_REQUIRE(h && start && beta && theta && sigma, "simlik: null argument");
+    MCML_REQUIRE(h->c.n > 0, "simlik: context has no model");
+    MCML_HIP(hipSetDevice(h->c.device));
+    return drv_simlik(h->c, start, nstart, trace, ext, beta, theta, sigma);
+}
+
+extern "C" int glmmr_mcml_ctx_hess(glmmr_mcml_ctx* h, const double* start, int nstart, double tol, int trace,
+                                   double* H)
+{
+    MCML_REQUIRE(h && start && H, "hess: null argument");
+    MCML_REQUIRE(h->c.n > 0 && tol > 0, "hess: context has no model / bad tol");
+    MCML_HIP(hipSetDevice(h->c.device));
+    return drv_hess(h->c, start, nstart, tol, trace, H);
+}
+
+extern "C" int glmmr_mcml_ctx_aic(glmmr_mcml_ctx* h, const double* beta_par, int nbeta, const double* cov_par,
+                                  int ncov, double* out)
+{
+    MCML_REQUIRE(h && beta_par && cov_par && out, "aic: null argument");
+    MCML_REQUIRE(h->c.n > 0, "aic: context has no model");
+    MCML_HIP(hipSetDevice(h->c.device));
+    return drv_aic(h->c, beta_par, nbeta, cov_par, ncov, out);
+}
+
+extern "C" int glmmr_mcml_ctx_full(glmmr_mcml_ctx* h, const double* start, int nstart, int mcnr, int m,
+                                   int maxiter, int warmup, double tol, int verbose, double lambda, int trace,
+                                   int refresh, int maxsteps, double target_accept, const glmmr_mcml_ext* ext,
+                                   double* beta, double* theta, double* sigma, int* converged, int* iters,
+                                   glmmr_mcml_hmc_diag* diag)
+{
+    MCML_REQUIRE(h && start && beta && theta && sigma, "mcml_full: null argument");
+    MCML_REQUIRE(h->c.n > 0, "mcml_full: context has no model");
+    MCML_HIP(hipSetDevice(h->c.device));
+    return drv_full(h->c, start, nstart, mcnr, m, maxiter, warmup, tol, verbose, lambda, trace, refresh, maxsteps,
+                    target_accept, ext, beta, theta, sigma, converged, iters, diag);
+}
+
+// ---- host-buffer mirrors of the Rcpp exports ----
+namespace {
+struct CtxGuard {
+    glmmr_mcml_ctx* h = nullptr;
+    ~CtxGuard() { if (h) glmmr_mcml_ctx_destroy(h); }
+};
+int open_ctx(const glmmr_mcml_problem* prob, const glmmr_mcml_ext* ext, CtxGuard& g)
+{
+    glmmr_mcml_dev_opts o{};
+    o.device = ext ? ext->device : 0; o.world = 1;
+    return glmmr_mcml_ctx_create(prob, &o, &g.h);
+}
+// the sparse exports pass the CSC pattern (Ap, Ai) of D (R6ModelExtMCML.R:193-195); D is
+// block diagonal, so the pattern must fit inside the blocks the cov matrix describes
+int check_pattern(const Ctx& c, const int32_t* Ap, const int32_t* Ai, int nnz)
+{
+    MCML_REQUIRE(Ap && Ai && nnz >= 0, "sparse: null pattern");
+    std::vector<int> blk(c.Q);
+    for (int b = 0; b < c.cov.B; ++b) for (int k = 0; k < c.cov.blocks[b].dim; ++k) blk[c.cov.blocks[b].matstart + k] = b;
+    MCML_REQUIRE(Ap[0] == 0 && Ap[c.Q] == nnz, "sparse: Ap does not describe %d columns / %d entries", c.Q, nnz);
+    for (int j = 0; j < c.Q; ++j)
+        for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
+            MCML_REQUIRE(Ai[p] >= 0 && Ai[p] < c.Q, "sparse: row index out of range");
+            MCML_REQUIRE(blk[Ai[p]] == blk[j], "sparse: entry (%d,%d) lies outside the covariance blocks", Ai[p], j);
+        }
+    return MCML_OK;
+}
+}  // namespace
+
+extern "C" int glmmr_mcml_optim(const glmmr_mcml_problem* prob, const double* u, int ucols, const double* start,
+                                int nstart, int trace, int mcnr, const glmmr_mcml_ext* ext, double* beta,
+                                double* theta, double* sigma)
+{
+    CtxGuard g;
+    MCML_TRY(open_ctx(prob, ext, g));
+    MCML_TRY(glmmr_mcml_set_u(g.h, u, prob->Q, ucols, ucols));
+    return glmmr_mcml_ctx_optim(g.h, start, nstart, trace, mcnr, ext, beta, theta, sigma);
+}
+
+extern "C" int glmmr_mcml_simlik(const glmmr_mcml_problem* prob, const double* u, int ucols, const double* start,
+                                 int nstart, int trace, const glmmr_mcml_ext* ext, double* beta, double* theta,
+                                 double* sigma)
+{
+    CtxGuard g;
+    MCML_TRY(open_ctx(prob, ext, g));
+    MCML_TRY(glmmr_mcml_set_u(g.h, u, prob->Q, ucols, ucols));
+    return glmmr_mcml_ctx_simlik(g.h, start, nstart, trace, ext, beta, theta, sigma);
+}
+
+extern "C" int glmmr_mcml_optim_sparse(const glmmr_mcml_problem* prob, const int32_t* Ap, const int32_t* Ai,
+                                       int nnz, const double* u, int ucols, const double* start, int nstart,
+                                       int trace, int mcnr, const glmmr_mcml_ext* ext, double* beta, double* theta,
+                                       double* sigma)
+{
+    CtxGuard g;
+    MCML_TRY(open_ctx(prob, ext, g));
+    MCML_TRY(check_pattern(g.h->c, Ap, Ai, nnz));
+    MCML_TRY(glmmr_mcml_set_u(g.h, u, prob->Q, ucols, ucols));
+    return glmmr_mcml_ctx_optim(g.h, start, nstart, trace, mcnr, ext, beta, theta, sigma);
+}
+
+extern "C" int glmmr_mcml_simlik_sparse(const glmmr_mcml_problem* prob, const int32_t* Ap, const int32_t* Ai,
+                                        int nnz, const double* u, int ucols, const double* start, int nstart,
+                                        int trace, const glmmr_mcml_ext* ext, double* beta, double* theta,
+                                        double* sigma)
+{
+    CtxGuard g;
+    MCML_TRY(open_ctx(prob, ext, g));
+    MCML_TRY(check_pattern(g.h->c, Ap, Ai, nnz));
+    MCML_TRY(glmmr_mcml_set_u(g.h, u, prob->Q, ucols, ucols));
+    return glmmr_mcml_ctx_simlik(g.h, start, nstart, trace, ext, beta, theta, sigma);
+}
+
+extern "C" int glmmr_mcml_hess(const glmmr_mcml_problem* prob, const double* u, int ucols, const double* start,
+                               int nstart, double tol, int trace, const glmmr_mcml_ext* ext, double* H)
+{
+    CtxGuard g;
+    MCML_TRY(open_ctx(prob, ext, g));
+    MCML_TRY(glmmr_mcml_set_u(g.h, u, prob->Q, ucols, ucols));
+    return glmmr_mcml_ctx_hess(g.h, start, nstart, tol, trace, H);
+}
+
+extern "C" int glmmr_mcml_hess_sparse(const glmmr_mcml_problem* prob, const int32_t* Ap, const int32_t* Ai,
+                                      int nnz, const double* u, int ucols, const double* start, int nstart,
+                                      double tol, int trace, const glmmr_mcml_ext* ext, double* H)
+{
+    CtxGuard g;
+    MCML_TRY(open_ctx(prob, ext, g));
+    MCML_TRY(check_pattern(g.h->c, Ap, Ai, nnz));
+    MCML_TRY(glmmr_mcml_set_u(g.h, u, prob->Q, ucols, ucols));
+    return glmmr_mcml_ctx_hess(g.h, start, nstart, tol, trace, H);
+}
+
+extern "C" int glmmr_mcml_aic(const glmmr_mcml_problem* prob, const double* u, int ucols, const double* beta_par,
+                              int nbeta, const double* cov_par, int ncov, const glmmr_mcml_ext* ext, double* out)
+{
+    CtxGuard g;
+    MCML_TRY(open_ctx(prob, ext, g));
+    MCML_TRY(glmmr_mcml_set_u(g.h, u, prob->Q, ucols, ucols));
+    return glmmr_mcml_ctx_aic(g.h, beta_par, nbeta, cov_par, ncov, out);
+}
+
+extern "C" int glmmr_mcml_full(const glmmr_mcml_problem* prob, const double* start, int nstart, int mcnr, int m,
+                               int maxiter, int warmup, double tol, int verbose, double lambda, int trace,
+                               int refresh, int maxsteps, double target_accept, const glmmr_mcml_ext* ext,
+                               double* beta, double* theta, double* sigma, int* converged, double* u, int ldu,
+                               int* ucols)
+{
+    CtxGuard g;
+    MCML_TRY(open_ctx(prob, ext, g));
+    int iters = 0;
+    MCML_TRY(glmmr_mcml_ctx_full(g.h, start, nstart, mcnr, m, maxiter, warmup, tol, verbose, lambda, trace, refresh,
+                                 maxsteps, target_accept, ext, beta, theta, sigma, converged, &iters, nullptr));
+    if (ucols) *ucols = g.h->c.mcols;
+    if (u) MCML_TRY(glmmr_mcml_get_u(g.h, u, ldu));
+    return MCML_OK;
+}
+
+extern "C" int glmmr_mcml_mcmc_sample(const double* Z, const double* L, const double* X, const double* y, int n,
+                                      int Q, int P, const double* beta, const char* family, const char* link,
+                                      int warmup, int nsamp, double lambda, double var_par, int trace, int refresh,
+                                      int maxsteps, double target_accept, const glmmr_mcml_ext* ext,
+                                      double* samples, int lds, int* ncols)
+{
+    (void)trace; (void)refresh;
+    MCML_REQUIRE(Z && L && X && y && beta && samples, "mcmc_sample: null argument");
+    glmmr_mcml_problem p{};
+    p.Z = Z; p.X = X; p.y = y; p.n = n; p.Q = Q; p.P = P; p.family = family; p.link = link;
+    CtxGuard g;
+    MCML_TRY(open_ctx(&p, ext, g));
+    MCML_TRY(glmmr_mcml_ctx_set_L(g.h, L, Q));
+    glmmr_mcml_hmc_opts ho{};
+    ho.warmup = warmup; ho.nsamp = nsamp; ho.adapt = 100; ho.lambda = lambda; ho.max_steps = maxsteps;
+    ho.target_accept = target_accept; ho.chains = (ext && ext->chains > 0) ? ext->chains : 1; ho.chain_offset = 0;
+    uint64_t seed = (ext && ext->seed) ? ext->seed : 0;
+    if (!seed) { std::random_device rd; seed = ((uint64_t)rd() << 32) | rd(); }
+    MCML_TRY(glmmr_mcml_ctx_hmc_sample(g.h, beta, var_par, &ho, seed, 0, nullptr, nullptr, nullptr, nullptr, nullptr, ncols));
+    return glmmr_mcml_get_u(g.h, samples, lds);
 }

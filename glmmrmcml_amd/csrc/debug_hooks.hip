@@ -106,3 +106,37 @@ extern "C" int glmmr_mcml_dbg_minstd(uint32_t seed, int n, double* out)
     MCML_HIP(hipMemcpy(out, b.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
     return MCML_OK;
 }
+
+// ---- host optimiser hooks (no GPU needed) ----
+#include "../../include/glmmr_mcml_c.h"
+#include "optim.h"
+#include <cmath>
+extern "C" int glmmr_mcml_dbg_bobyqa(glmmr_mcml_objective f, void* user, int n, const double* x0,
+                                     const double* lower, const double* upper, double rhobeg, double rhoend,
+                                     int maxfun, double* x_out, double* f_out, int* nfev_out)
+{
+    MCML_REQUIRE(f && n > 0 && x0 && x_out, "dbg_bobyqa: bad argument");
+    objective_fn obj = [&](const std::vector<double>& x, double* v) { *v = f(x.data(), n, user); return 0; };
+    std::vector<double> x(x0, x0 + n), lo(n, -HUGE_VAL), up(n, HUGE_VAL);
+    if (lower) lo.assign(lower, lower + n);
+    if (upper) up.assign(upper, upper + n);
+    BobyqaOpts o; o.rhobeg = rhobeg; o.rhoend = rhoend; if (maxfun > 0) o.maxfun = maxfun;
+    BobyqaResult r;
+    MCML_TRY(bobyqa(obj, x, lo, up, o, &r));
+    for (int i = 0; i < n; ++i) x_out[i] = r.x[i];
+    if (f_out) *f_out = r.fval;
+    if (nfev_out) *nfev_out = r.nfev;
+    return MCML_OK;
+}
+extern "C" int glmmr_mcml_dbg_fd_hessian(glmmr_mcml_objective f, void* user, int n, const double* x, double ndeps,
+                                         int usebounds, const double* lower, const double* upper, double* H)
+{
+    MCML_REQUIRE(f && n > 0 && x && H, "dbg_fd_hessian: bad argument");
+    objective_fn obj = [&](const std::vector<double>& xx, double* v) { *v = f(xx.data(), n, user); return 0; };
+    std::vector<double> xv(x, x + n), nd(n, ndeps), lo(n, -HUGE_VAL), up(n, HUGE_VAL), h;
+    if (lower) lo.assign(lower, lower + n);
+    if (upper) up.assign(upper, upper + n);
+    MCML_TRY(fd_hessian(obj, xv, nd, usebounds != 0, lo, up, &h));
+    for (int i = 0; i < n * n; ++i) H[i] = h[i];
+    return MCML_OK;
+}

@@ -1,0 +1,288 @@
+// drivers.hip -- the algorithm objects and drivers above the kernels:
+//   objective functors D_/L_/F_likelihood        likelihood.h:31-110
+//   mcmloptim::{d_optim,l_optim,f_optim,mcnr,f_hess}   mcmloptim.h:56-113,198-236,333-355
+//   drivers mcml_full, mcmc_sample                src/mcml_full.cpp:41-148,314-338
+//   mcml_optim, mcml_simlik, mcml_hess, aic_mcml  src/mcml_optim.cpp:35-392
+// Host code; every objective evaluation runs on the device with u, Z, X, y
+// resident and returns one scalar.
+//
+// Deliberate departures from the reference:
+//   D4  the importance ratio exp(ll+logl)/exp(denom) underflows to NaN for any
+//       realistic n (likelihood.h:101-105): evaluated as -(ll + logl - denom).
+//   D3  mcnr's OpenMP race on W_/zu_: the statistics here are those of the
+//       serial loop.
+//   D11 the sampler is re-initialised every MCML iteration exactly as the
+//       reference does (mhmcmc.h:127), with seeds derived from (seed, iteration).
+#include "../../include/glmmr_mcml_c.h"
+#include "ctx.h"
+#include "optim.h"
+#include <cmath>
+#include <random>
+
+namespace mcml {
+
+int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_opts* o, uint64_t seed,
+               uint32_t iter_idx, const double* inj_init, const double* inj_mom, uint8_t* flags_out,
+               double* probs_out, glmmr_mcml_hmc_diag* diag, int* ncols_out);
+
+static bool is_gaussian(int flink) { return flink == 7 || flink == 8; }
+// family_=="gaussian"||"Gamma"||"beta" (likelihood.h:61,95): the map keys are
+// lower-case "gamma" (mcmlmodel.h:83-85), so "Gamma" never reaches this point
+static bool has_var_par(int flink) { return flink == 7 || flink == 8 || flink == 12; }
+
+// ---- device-backed scalar evaluations (all-reduced over ranks) ----
+static int eval_loglik(Ctx& c, const double* beta, double var_par, double* ll)
+{
+    MCML_TRY(model_update_beta(c, beta));
+    double s = 0;
+    MCML_TRY(model_loglik_sum(c, var_par, &s));
+    double tot[2] = {s, (double)c.niter};
+    MCML_TRY(allreduce_host(c, tot, 2));
+    *ll = tot[0] / tot[1];
+    return MCML_OK;
+}
+
+static int eval_mvn(Ctx& c, const double* theta, double* logl)
+{
+    double s = 0;
+    MCML_TRY(mvn_loglik_sum(c, theta, &s));
+    double tot[2] = {s, (double)c.mcols};
+    MCML_TRY(allreduce_host(c, tot, 2));
+    *logl = tot[0] / tot[1];
+    return MCML_OK;
+}
+
+// mcmloptim<T> (mcmloptim.h:16-369)
+struct McmlOptim {
+    Ctx& c;
+    int P, R;
+    std::vector<double> beta, theta, cov_par_fix;
+    double sigma;
+    int trace, maxfun;
+    double model_var_par;     // M_->var_par_
+
+    McmlOptim(Ctx& ctx, const double* start, int trace_, int maxfun_, double var_par0)
+        : c(ctx), P(ctx.P), R(ctx.cov.npar), trace(trace_), maxfun(maxfun_), model_var_par(var_par0)
+    {
+        beta.assign(start, start + P);
+        theta.assign(start + P, start + P + R);
+        cov_par_fix = theta;
+        sigma = is_gaussian(c.flink) ? start[P + R] : 0;         // mcmloptim.h:30
+    }
+
+    BobyqaOpts bopts() const { BobyqaOpts o; o.iprint = trace; if (maxfun > 0) o.maxfun = maxfun; return o; }
+
+    // d_optim (mcmloptim.h:56-68), D_likelihood (likelihood.h:40-45)
+    int d_optim()
+    {
+        objective_fn f = [&](const std::vector<double>& par, double* v) {
+            double logl; MCML_TRY(eval_mvn(c, par.data(), &logl)); *v = -1 * logl; return (int)MCML_OK; };
+        std::vector<double> lo(R, 1e-6), up(R, HUGE_VAL);
+        BobyqaResult r;
+        MCML_TRY(bobyqa(f, theta, lo, up, bopts(), &r));
+        theta = r.x;
+        return MCML_OK;
+    }
+
+    // l_optim (mcmloptim.h:71-88), L_likelihood (likelihood.h:57-64)
+    int l_optim()
+    {
+        if (c.flink == 12) { set_error("l_optim: beta family is not built (reference reads par[P] out of range, defect D8)"); return MCML_EUNSUPPORTED; }
+        const bool g = is_gaussian(c.flink);
+        objective_fn f = [&](const std::vector<double>& par, double* v) {
+            model_var_par = has_var_par(c.flink) ? par[P] : 0.0;   // fix_var_ = false, fix_var_par_ = 0
+            double ll; MCML_TRY(eval_loglik(c, par.data(), model_var_par, &ll)); *v = -1 * ll; return (int)MCML_OK; };
+        std::vector<double> x = beta, lo(P, -HUGE_VAL), up(P, HUGE_VAL);
+        if (g) { x.push_back(sigma); lo.push_back(0.0); up.push_back(HUGE_VAL); }
+        BobyqaResult r;
+        MCML_TRY(bobyqa(f, x, lo, up, bopts(), &r));
+        beta.assign(r.x.begin(), r.x.begin() + P);
+        if (g) sigma = r.x[P];
+        return MCML_OK;
+    }
+
+    // mcnr (mcmloptim.h:198-236)
+    int mcnr()
+    {
+        MCML_TRY(model_update_beta(c, beta.data()));
+        std::vector<double> st((size_t)P * P + P + 2), nb(P);
+        MCML_TRY(model_mcnr_stats(c, model_var_par, st.data()));
+        double s = 0;
+        MCML_TRY(mcnr_finish(P, st.data(), beta.data(), nb.data(), &s));
+        beta = nb; sigma = s;
+        return MCML_OK;
+    }
+
+    // F_likelihood::operator() (likelihood.h:88-109) with fix_var = true
+    objective_fn make_F(bool importance, double fix_var_par, double denomD)
+    {
+        return [this, importance, fix_var_par, denomD](const std::vector<double>& par, double* v) {
+            model_var_par = fix_var_par;
+            double ll, logl;
+            MCML_TRY(eval_loglik(c, par.data(), model_var_par, &ll));
+            MCML_TRY(eval_mvn(c, par.data() + P, &logl));
+            *v = importance ? -1.0 * (ll + logl - denomD) : -1.0 * (ll + logl);
+            return (int)MCML_OK; };
+    }
+
+    // f_optim (mcmloptim.h:91-113)
+    int f_optim()
+    {
+        const bool g = is_gaussian(c.flink);
+        double denomD = 0;
+        MCML_TRY(eval_mvn(c, cov_par_fix.data(), &denomD));      // constant in the parameters
+        objective_fn f = make_F(true, sigma, denomD);
+        std::vector<double> x = beta, lo(P, -HUGE_VAL), up;
+        for (int i = 0; i < R; ++i) { x.push_back(theta[i]); lo.push_back(1e-6); }
+        if (g) { x.push_back(sigma); lo.push_back(0.0); }
+        up.assign(x.size(), HUGE_VAL);
+        BobyqaResult r;
+        MCML_TRY(bobyqa(f, x, lo, up, bopts(), &r));
+        beta.assign(r.x.begin(), r.x.begin() + P);
+        theta.assign(r.x.begin() + P, r.x.begin() + P + R);
+        if (g) sigma = r.x[P + R];
+        return MCML_OK;
+    }
+
+    // f_hess (mcmloptim.h:333-355)
+    int f_hess(double tol, double* H)
+    {
+        objective_fn f = make_F(false, sigma, 0.0);
+        const int nv = P + R;
+        std::vector<double> x = beta, lo(P, -HUGE_VAL), up(nv, HUGE_VAL), nd(nv, tol), h;
+        for (int i = 0; i < R; ++i) { x.push_back(theta[i]); lo.push_back(1e-6); }
+        MCML_TRY(fd_hessian(f, x, nd, true, lo, up, &h));
+        memcpy(H, h.data(), sizeof(double) * (size_t)nv * nv);
+        return MCML_OK;
+    }
+};
+
+static uint64_t default_seed(const glmmr_mcml_ext* e)
+{
+    if (e && e->seed) return e->seed;
+    std::random_device rd;            // what the reference does (mhmcmc.h:55)
+    return ((uint64_t)rd() << 32) | rd();
+}
+
+// ---------------------------------------------------------------- ctx-level drivers
+int drv_optim(Ctx& c, const double* start, int nstart, int trace, int mcnr, const glmmr_mcml_ext* e,
+              double* beta, double* theta, double* sigma)
+{
+    const int P = c.P, R = c.cov.npar;
+    MCML_REQUIRE(start && nstart >= P + R + (is_gaussian(c.flink) ? 1 : 0), "start has %d values, need %d", nstart, P + R + (is_gaussian(c.flink) ? 1 : 0));
+    MCML_REQUIRE(c.mcols > 0, "no samples u set");
+    McmlOptim mc(c, start, trace, e ? e->maxfun : 0, 1.0);      // model built with var_par = 1 (mcml_optim.cpp:51)
+    if (!mcnr) MCML_TRY(mc.l_optim()); else MCML_TRY(mc.mcnr());
+    MCML_TRY(mc.d_optim());
+    memcpy(beta, mc.beta.data(), sizeof(double) * P);
+    memcpy(theta, mc.theta.data(), sizeof(double) * R);
+    *sigma = mc.sigma;
+    return MCML_OK;
+}
+
+int drv_simlik(Ctx& c, const double* start, int nstart, int trace, const glmmr_mcml_ext* e, double* beta,
+               double* theta, double* sigma)
+{
+    const int P = c.P, R = c.cov.npar;
+    MCML_REQUIRE(start && nstart >= P + R + (is_gaussian(c.flink) ? 1 : 0), "start too short");
+    MCML_REQUIRE(c.mcols > 0, "no samples u set");
+    McmlOptim mc(c, start, trace, e ? e->maxfun : 0, 1.0);
+    MCML_TRY(mc.f_optim());
+    memcpy(beta, mc.beta.data(), sizeof(double) * P);
+    memcpy(theta, mc.theta.data(), sizeof(double) * R);
+    *sigma = mc.sigma;
+    return MCML_OK;
+}
+
+int drv_hess(Ctx& c, const double* start, int nstart, double tol, int trace, double* H)
+{
+    const int P = c.P, R = c.cov.npar;
+    MCML_REQUIRE(start && nstart >= P + R + (is_gaussian(c.flink) ? 1 : 0), "start too short");
+    MCML_REQUIRE(c.mcols > 0, "no samples u set");
+    McmlOptim mc(c, start, trace, 0, 1.0);
+    return mc.f_hess(tol, H);
+}
+
+// aic_mcml (mcml_optim.cpp:356-392)
+int drv_aic(Ctx& c, const double* beta_par, int nbeta, const double* cov_par, int ncov, double* out)
+{
+    const int P = c.P;
+    const bool var = (c.flink == 7 || c.flink == 8 || c.flink == 12);
+    MCML_REQUIRE(nbeta >= P + (var ? 1 : 0) && ncov >= c.cov.npar, "aic_mcml: parameter vectors too short");
+    MCML_REQUIRE(c.mcols > 0, "no samples u set");
+    const double var_par = var ? beta_par[P] : 0;
+    const int dof = nbeta + ncov;
+    double dmv, ll;
+    MCML_TRY(eval_mvn(c, cov_par, &dmv));
+    MCML_TRY(eval_loglik(c, beta_par, var_par, &ll));
+    *out = (-2 * (ll + dmv) + 2 * dof);
+    return MCML_OK;
+}
+
+// mcml_full (mcml_full.cpp:41-148)
+int drv_full(Ctx& c, const double* start, int nstart, int mcnr, int m, int maxiter, int warmup, double tol,
+             int verbose, double lambda, int trace, int refresh, int maxsteps, double target_accept,
+             const glmmr_mcml_ext* e, double* beta_out, double* theta_out, double* sigma_out,
+             int* converged_out, int* iters_out, glmmr_mcml_hmc_diag* last_diag)
+{
+    (void)refresh;
+    const int P = c.P, R = c.cov.npar;
+    MCML_REQUIRE(start && nstart >= P + R + 1, "mcml_full: start needs c(beta, theta, sigma|1) = %d values", P + R + 1);
+    MCML_REQUIRE(m > 0 && maxiter >= 1, "mcml_full: bad m / maxiter");
+    std::vector<double> theta(start + P, start + P + R), beta(start, start + P);
+    double var_par = is_gaussian(c.flink) ? start[nstart - 1] : 1;          // :65
+    const uint64_t seed = default_seed(e);
+    const int chains = (e && e->chains > 0) ? e->chains : 1;
+    MCML_TRY(mvn_gen_L(c, theta.data(), true));                               // :66-68
+    MCML_TRY(model_update_beta(c, beta.data()));
+    MCML_TRY(model_update_L(c));
+    McmlOptim mc(c, start, trace, e ? e->maxfun : 0, var_par);                // :71
+    double maxdiff = 1;
+    int iter = 1;
+    bool converged = false;
+    glmmr_mcml_hmc_opts ho{};
+    ho.warmup = warmup; ho.nsamp = m; ho.adapt = 100; ho.lambda = lambda; ho.max_steps = maxsteps;
+    ho.target_accept = target_accept; ho.chains = chains; ho.chain_offset = c.rank * chains;
+    while (maxdiff > tol && iter <= maxiter) {                                 // :83
+        glmmr_mcml_hmc_diag dg{};
+        MCML_TRY(hmc_sample(c, beta.data(), var_par, &ho, seed, (uint32_t)iter, nullptr, nullptr, nullptr,
+                            nullptr, &dg, nullptr));                           // :92
+        if (last_diag) *last_diag = dg;
+        mc.model_var_par = var_par;
+        if (!mcnr) MCML_TRY(mc.l_optim()); else MCML_TRY(mc.mcnr());           // :95-99
+        MCML_TRY(mc.d_optim());                                                // :101
+        const std::vector<double>& nb = mc.beta; const std::vector<double>& nt = mc.theta;
+        double new_var_par = 1;
+        if (is_gaussian(c.flink)) new_var_par = mc.sigma;                      // :105
+        else new_var_par = var_par;
+        maxdiff = 0;
+        for (int i = 0; i < P; ++i) maxdiff = std::max(maxdiff, std::fabs(beta[i] - nb[i]));
+        for (int i = 0; i < R; ++i) maxdiff = std::max(maxdiff, std::fabs(theta[i] - nt[i]));
+        maxdiff = std::max(maxdiff, std::fabs(var_par - new_var_par));
+        if (maxdiff < tol) converged = true;                                   // :113
+        beta = nb; theta = nt; var_par = new_var_par;
+        if (!converged) {                                                      // :119-126
+            MCML_TRY(mvn_gen_L(c, theta.data(), true));
+            MCML_TRY(model_update_beta(c, beta.data()));
+            MCML_TRY(model_update_L(c));
+        }
+        if (verbose && c.rank == 0) {
+            printf("Iter %d  beta:", iter);
+            for (double b : beta) printf(" %.6g", b);
+            printf("  theta:");
+            for (double t : theta) printf(" %.6g", t);
+            if (is_gaussian(c.flink)) printf("  sigma: %.6g", var_par);
+            printf("  max diff %.4g  accept %.3f%s\n", maxdiff, dg.accept_rate, converged ? "  CONVERGED" : "");
+            fflush(stdout);
+        }
+        ++iter;
+    }
+    memcpy(beta_out, beta.data(), sizeof(double) * P);
+    memcpy(theta_out, theta.data(), sizeof(double) * R);
+    *sigma_out = var_par;
+    if (converged_out) *converged_out = converged ? 1 : 0;
+    if (iters_out) *iters_out = iter - 1;
+    return MCML_OK;
+}
+
+}  // namespace mcml

@@ -126,6 +126,83 @@ int glmmr_mcml_ctx_hmc_sample(glmmr_mcml_ctx* ctx, const double* beta, double va
 /* Mirrors of the Rcpp exports (host buffers in, host buffers out)            */
 /* ------------------------------------------------------------------------- */
 
+/* What the reference leaves to chance or to its dependencies' defaults. */
+typedef struct glmmr_mcml_ext {
+    uint64_t seed;      /* 0: draw one from std::random_device as the reference does (mhmcmc.h:55) */
+    int      chains;    /* <= 1: the reference's single sequential chain; C: C concurrent chains */
+    int      maxfun;    /* objective evaluations per optimiser call; 0 = 10000 (minqa default) */
+    int      device;    /* HIP device ordinal */
+} glmmr_mcml_ext;
+
+/* columns of u a sampler call returns for m samples: m + 1 for one chain
+ * (mhmcmc.h:126), chains * ceil(m / chains) otherwise */
+int glmmr_mcml_sample_cols(int m, int chains);
+int glmmr_mcml_ctx_ncols(glmmr_mcml_ctx* ctx);
+int glmmr_mcml_ctx_npar(glmmr_mcml_ctx* ctx);
+
+/* The same drivers on a resident context (what bench.py times). */
+int glmmr_mcml_ctx_optim(glmmr_mcml_ctx* ctx, const double* start, int nstart, int trace, int mcnr,
+                         const glmmr_mcml_ext* ext, double* beta, double* theta, double* sigma);
+int glmmr_mcml_ctx_simlik(glmmr_mcml_ctx* ctx, const double* start, int nstart, int trace,
+                          const glmmr_mcml_ext* ext, double* beta, double* theta, double* sigma);
+int glmmr_mcml_ctx_hess(glmmr_mcml_ctx* ctx, const double* start, int nstart, double tol, int trace,
+                        double* H /* (P+R) x (P+R) */);
+int glmmr_mcml_ctx_aic(glmmr_mcml_ctx* ctx, const double* beta_par, int nbeta, const double* cov_par,
+                       int ncov, double* out);
+int glmmr_mcml_ctx_full(glmmr_mcml_ctx* ctx, const double* start, int nstart, int mcnr, int m, int maxiter,
+                        int warmup, double tol, int verbose, double lambda, int trace, int refresh,
+                        int maxsteps, double target_accept, const glmmr_mcml_ext* ext, double* beta,
+                        double* theta, double* sigma, int* converged, int* iters,
+                        glmmr_mcml_hmc_diag* last_diag);
+
+/* mcml_full(cov, data, eff_range, Z, X, y, family, link, start, mcnr, m, maxiter, warmup, tol,
+ *           verbose, lambda, trace, refresh, maxsteps, target_accept)
+ *   -> list(beta, theta, sigma, converged, u)               -- src/mcml_full.cpp:41-148
+ * u receives Q x *ucols columns (glmmr_mcml_sample_cols(m, chains)). */
+int glmmr_mcml_full(const glmmr_mcml_problem* prob, const double* start, int nstart, int mcnr, int m,
+                    int maxiter, int warmup, double tol, int verbose, double lambda, int trace,
+                    int refresh, int maxsteps, double target_accept, const glmmr_mcml_ext* ext,
+                    double* beta, double* theta, double* sigma, int* converged, double* u, int ldu,
+                    int* ucols);
+
+/* mcmc_sample(Z, L, X, y, beta, family, link, warmup, nsamp, lambda, var_par, trace, refresh,
+ *             maxsteps, target_accept) -> Q x (nsamp+1)      -- src/mcml_full.cpp:314-338 */
+int glmmr_mcml_mcmc_sample(const double* Z, const double* L, const double* X, const double* y, int n,
+                           int Q, int P, const double* beta, const char* family, const char* link,
+                           int warmup, int nsamp, double lambda, double var_par, int trace, int refresh,
+                           int maxsteps, double target_accept, const glmmr_mcml_ext* ext,
+                           double* samples, int lds, int* ncols);
+
+/* mcml_optim(cov, data, eff_range, Z, X, y, u, family, link, start, trace, mcnr)
+ *   -> list(beta, theta, sigma)                              -- src/mcml_optim.cpp:35-68 */
+int glmmr_mcml_optim(const glmmr_mcml_problem* prob, const double* u, int ucols, const double* start,
+                     int nstart, int trace, int mcnr, const glmmr_mcml_ext* ext, double* beta,
+                     double* theta, double* sigma);
+/* mcml_simlik(..., u, family, link, start, trace)            -- src/mcml_optim.cpp:90-117 */
+int glmmr_mcml_simlik(const glmmr_mcml_problem* prob, const double* u, int ucols, const double* start,
+                      int nstart, int trace, const glmmr_mcml_ext* ext, double* beta, double* theta,
+                      double* sigma);
+/* mcml_optim_sparse / mcml_simlik_sparse (..., Ap, Ai, ...)  -- src/mcml_optim.cpp:147-184,210-239.
+ * D is block diagonal, so the (Ap, Ai) pattern is checked against the blocks and the same
+ * block-factorised path is used (the reference's sparse loglik reads column 0 of u for every
+ * sample, defect D1: not reproduced). */
+int glmmr_mcml_optim_sparse(const glmmr_mcml_problem* prob, const int32_t* Ap, const int32_t* Ai, int nnz,
+                            const double* u, int ucols, const double* start, int nstart, int trace,
+                            int mcnr, const glmmr_mcml_ext* ext, double* beta, double* theta,
+                            double* sigma);
+int glmmr_mcml_simlik_sparse(const glmmr_mcml_problem* prob, const int32_t* Ap, const int32_t* Ai, int nnz,
+                             const double* u, int ucols, const double* start, int nstart, int trace,
+                             const glmmr_mcml_ext* ext, double* beta, double* theta, double* sigma);
+/* mcml_hess(..., u, family, link, start, tol = 1e-5, trace)  -- src/mcml_optim.cpp:263-285 */
+int glmmr_mcml_hess(const glmmr_mcml_problem* prob, const double* u, int ucols, const double* start,
+                    int nstart, double tol, int trace, const glmmr_mcml_ext* ext, double* H);
+int glmmr_mcml_hess_sparse(const glmmr_mcml_problem* prob, const int32_t* Ap, const int32_t* Ai, int nnz,
+                           const double* u, int ucols, const double* start, int nstart, double tol,
+                           int trace, const glmmr_mcml_ext* ext, double* H);
+/* aic_mcml(..., u, family, link, beta_par, cov_par)          -- src/mcml_optim.cpp:356-392 */
+int glmmr_mcml_aic(const glmmr_mcml_problem* prob, const double* u, int ucols, const double* beta_par,
+                   int nbeta, const double* cov_par, int ncov, const glmmr_mcml_ext* ext, double* out);
+
 /* mvn_ll(cov, data, eff_range, gamma, u)  -- src/mcml_optim.cpp:406-414 */
 int glmmr_mcml_mvn_ll(const int32_t* cov, int cov_rows, const double* data, int data_len,
                       const double* eff_range, int eff_len, const double* gamma, int ngamma,
@@ -141,6 +218,13 @@ int glmmr_mcml_dbg_log_prob_grad(glmmr_mcml_ctx* ctx, const double* beta, double
 /* RNG contract on the device: Philox/AS241 normals and the minstd canonical stream */
 int glmmr_mcml_dbg_normals(uint64_t seed, uint32_t chain, uint32_t prop, uint32_t tag, int n, double* out);
 int glmmr_mcml_dbg_minstd(uint32_t seed, int n, double* out);
+/* host optimiser / finite differences on a caller-supplied objective (CPU only) */
+typedef double (*glmmr_mcml_objective)(const double* x, int n, void* user);
+int glmmr_mcml_dbg_bobyqa(glmmr_mcml_objective f, void* user, int n, const double* x0, const double* lower,
+                          const double* upper, double rhobeg, double rhoend, int maxfun, double* x_out,
+                          double* f_out, int* nfev_out);
+int glmmr_mcml_dbg_fd_hessian(glmmr_mcml_objective f, void* user, int n, const double* x, double ndeps,
+                              int usebounds, const double* lower, const double* upper, double* H);
 int glmmr_mcml_dbg_dgemm_bench(int M, int N, int K, int b_nmajor, int iters, int force_tile,
                                double* ms_per_launch);
 

@@ -35,6 +35,10 @@ class HmcOpts(C.Structure):
                 ("chain_offset", C.c_int)]
 
 
+class Ext(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("chains", C.c_int), ("maxfun", C.c_int), ("device", C.c_int)]
+
+
 class HmcDiag(C.Structure):
     _fields_ = [("accept_rate", C.c_double), ("mean_e", C.c_double), ("min_e", C.c_double),
                 ("max_e", C.c_double), ("max_steps_used", C.c_int), ("leapfrog_total", C.c_longlong)]
@@ -189,9 +193,197 @@ class Context:
         return diag
 
 
+    # -- drivers on the resident context
+    def _ext(self, seed, chains, maxfun):
+        return Ext(int(seed or 0), int(chains or 1), int(maxfun or 0), 0)
+
+    def npar(self):
+        return _lib.lib().glmmr_mcml_ctx_npar(self._h)
+
+    def mcml_optim(self, start, trace=0, mcnr=False, maxfun=0):
+        start = _f(start).ravel(); R = self.npar()
+        b = np.zeros(self.P); t = np.zeros(R); sg = C.c_double()
+        e = self._ext(0, 1, maxfun)
+        _lib.check(_lib.lib().glmmr_mcml_ctx_optim(self._h, _p(start), start.size, int(trace), int(mcnr),
+                                                   C.byref(e), _p(b), _p(t), C.byref(sg)))
+        return dict(beta=b, theta=t, sigma=sg.value)
+
+    def mcml_simlik(self, start, trace=0, maxfun=0):
+        start = _f(start).ravel(); R = self.npar()
+        b = np.zeros(self.P); t = np.zeros(R); sg = C.c_double()
+        e = self._ext(0, 1, maxfun)
+        _lib.check(_lib.lib().glmmr_mcml_ctx_simlik(self._h, _p(start), start.size, int(trace), C.byref(e),
+                                                    _p(b), _p(t), C.byref(sg)))
+        return dict(beta=b, theta=t, sigma=sg.value)
+
+    def mcml_hess(self, start, tol=1e-5, trace=0):
+        start = _f(start).ravel(); nv = self.P + self.npar()
+        H = np.zeros((nv, nv), order="F")
+        _lib.check(_lib.lib().glmmr_mcml_ctx_hess(self._h, _p(start), start.size, C.c_double(tol), int(trace), _p(H)))
+        return H
+
+    def aic_mcml(self, beta_par, cov_par):
+        bp = _f(beta_par).ravel(); cp = _f(cov_par).ravel()
+        out = C.c_double()
+        _lib.check(_lib.lib().glmmr_mcml_ctx_aic(self._h, _p(bp), bp.size, _p(cp), cp.size, C.byref(out)))
+        return out.value
+
+    def mcml_full(self, start, mcnr=False, m=500, maxiter=30, warmup=500, tol=1e-3, verbose=False,
+                  lambda_=0.05, trace=0, refresh=500, maxsteps=100, target_accept=0.9, seed=0, chains=1,
+                  maxfun=0):
+        start = _f(start).ravel(); R = self.npar()
+        b = np.zeros(self.P); t = np.zeros(R); sg = C.c_double(); conv = C.c_int(); it = C.c_int()
+        d = HmcDiag()
+        e = self._ext(seed, chains, maxfun)
+        _lib.check(_lib.lib().glmmr_mcml_ctx_full(
+            self._h, _p(start), start.size, int(mcnr), int(m), int(maxiter), int(warmup), C.c_double(tol),
+            int(verbose), C.c_double(lambda_), int(trace), int(refresh), int(maxsteps), C.c_double(target_accept),
+            C.byref(e), _p(b), _p(t), C.byref(sg), C.byref(conv), C.byref(it), C.byref(d)))
+        self.mcols = _lib.lib().glmmr_mcml_ctx_ncols(self._h)
+        return dict(beta=b, theta=t, sigma=sg.value, converged=bool(conv.value), iters=it.value,
+                    accept_rate=d.accept_rate, mean_e=d.mean_e, leapfrog_total=d.leapfrog_total)
+
+    def profile(self, enable=True, reset=False):
+        out = np.zeros(4)
+        _lib.check(_lib.lib().glmmr_mcml_ctx_profile(self._h, int(enable), int(reset), _p(out)))
+        return dict(fwd_ms=out[0], fwd_n=int(out[1]), bwd_ms=out[2], bwd_n=int(out[3]))
+
+
+def _problem(cov, data, eff_range, Z, X, y, family, link):
+    keep = dict(cov=_i(cov), data=_f(data).ravel(), eff=_f(eff_range).ravel(), Z=_f(Z), X=_f(X), y=_f(y).ravel())
+    p = Problem()
+    p.cov = keep["cov"].ctypes.data_as(c_ip); p.cov_rows = keep["cov"].shape[0]
+    p.data = _p(keep["data"]); p.data_len = keep["data"].size
+    p.eff_range = _p(keep["eff"]); p.eff_len = keep["eff"].size
+    p.Z = _p(keep["Z"]); p.X = _p(keep["X"]); p.y = _p(keep["y"])
+    p.n, p.Q = keep["Z"].shape; p.P = keep["X"].shape[1]
+    p.family = family.encode(); p.link = link.encode()
+    return p, keep
+
+
 # ---------------------------------------------------------------------------
 # Mirrors of the Rcpp exports
 # ---------------------------------------------------------------------------
+def mcml_full(cov, data, eff_range, Z, X, y, family, link, start, mcnr=False, m=500, maxiter=30,
+              warmup=500, tol=1e-3, verbose=True, lambda_=0.05, trace=0, refresh=500, maxsteps=100,
+              target_accept=0.9, seed=0, chains=1, maxfun=0):
+    """mcml_full(...) -> dict(beta, theta, sigma, converged, u)   (src/mcml_full.cpp:41-148).
+    seed / chains / maxfun are the build's additions (reference: random_device, 1 chain, 10000)."""
+    p, keep = _problem(cov, data, eff_range, Z, X, y, family, link)
+    start = _f(start).ravel()
+    L = _lib.lib()
+    ncol = L.glmmr_mcml_sample_cols(int(m), int(chains))
+    R = int(start.size - p.P - 1)
+    b = np.zeros(p.P); t = np.zeros(R); sg = C.c_double(); conv = C.c_int(); uc = C.c_int()
+    u = np.zeros((p.Q, ncol), order="F")
+    e = Ext(int(seed), int(chains), int(maxfun), 0)
+    _lib.check(L.glmmr_mcml_full(C.byref(p), _p(start), start.size, int(mcnr), int(m), int(maxiter), int(warmup),
+                                 C.c_double(tol), int(verbose), C.c_double(lambda_), int(trace), int(refresh),
+                                 int(maxsteps), C.c_double(target_accept), C.byref(e), _p(b), _p(t), C.byref(sg),
+                                 C.byref(conv), _p(u), p.Q, C.byref(uc)))
+    return dict(beta=b, theta=t, sigma=sg.value, converged=bool(conv.value), u=u[:, :uc.value])
+
+
+def mcmc_sample(Z, L, X, y, beta, family, link, warmup, nsamp, lambda_, var_par=1, trace=0, refresh=500,
+                maxsteps=100, target_accept=0.9, seed=0, chains=1):
+    """mcmc_sample(...) -> Q x (nsamp+1) matrix of u = L v   (src/mcml_full.cpp:314-338)"""
+    Z = _f(Z); Lm = _f(L); X = _f(X); y = _f(y).ravel(); beta = _f(beta).ravel()
+    n, Q = Z.shape
+    lib = _lib.lib()
+    ncol = lib.glmmr_mcml_sample_cols(int(nsamp), int(chains))
+    out = np.zeros((Q, ncol), order="F"); nc = C.c_int()
+    e = Ext(int(seed), int(chains), 0, 0)
+    _lib.check(lib.glmmr_mcml_mcmc_sample(_p(Z), _p(Lm), _p(X), _p(y), n, Q, X.shape[1], _p(beta),
+                                          family.encode(), link.encode(), int(warmup), int(nsamp),
+                                          C.c_double(lambda_), C.c_double(var_par), int(trace), int(refresh),
+                                          int(maxsteps), C.c_double(target_accept), C.byref(e), _p(out), Q,
+                                          C.byref(nc)))
+    return out[:, :nc.value]
+
+
+def _fit_call(fn, prob_args, u, start, extra, sparse=None, maxfun=0):
+    p, keep = _problem(*prob_args)
+    u = _f(u); start = _f(start).ravel()
+    R = int(start.size - p.P - 1) if start.size > p.P + 1 else 0
+    b = np.zeros(p.P); t = np.zeros(max(R, 64)); sg = C.c_double()
+    e = Ext(0, 1, int(maxfun), 0)
+    args = [C.byref(p)]
+    if sparse is not None:
+        Ap, Ai = _i(sparse[0]).ravel(), _i(sparse[1]).ravel()
+        args += [Ap.ctypes.data_as(c_ip), Ai.ctypes.data_as(c_ip), Ai.size]
+    args += [_p(u), u.shape[1], _p(start), start.size] + extra + [C.byref(e), _p(b), _p(t), C.byref(sg)]
+    _lib.check(fn(*args))
+    return b, t, sg.value
+
+
+def _npar_of(cov):
+    fnpar = [0, 1, 1, 1, 2, 2, 1, 2, 2, 2, 2, 2, 2, 2, 1]
+    cov = _i(cov)
+    return int(max(cov[r, 4] + fnpar[cov[r, 2]] for r in range(cov.shape[0])))
+
+
+def mcml_optim(cov, data, eff_range, Z, X, y, u, family, link, start, trace=0, mcnr=False, maxfun=0):
+    """mcml_optim(...) -> dict(beta, theta, sigma)   (src/mcml_optim.cpp:35-68)"""
+    b, t, s = _fit_call(_lib.lib().glmmr_mcml_optim, (cov, data, eff_range, Z, X, y, family, link), u, start,
+                        [int(trace), int(mcnr)], maxfun=maxfun)
+    return dict(beta=b, theta=t[:_npar_of(cov)], sigma=s)
+
+
+def mcml_simlik(cov, data, eff_range, Z, X, y, u, family, link, start, trace=0, maxfun=0):
+    """mcml_simlik(...)   (src/mcml_optim.cpp:90-117)"""
+    b, t, s = _fit_call(_lib.lib().glmmr_mcml_simlik, (cov, data, eff_range, Z, X, y, family, link), u, start,
+                        [int(trace)], maxfun=maxfun)
+    return dict(beta=b, theta=t[:_npar_of(cov)], sigma=s)
+
+
+def mcml_optim_sparse(cov, data, eff_range, Ap, Ai, Z, X, y, u, family, link, start, trace=0, mcnr=False,
+                      maxfun=0):
+    """mcml_optim_sparse(...)   (src/mcml_optim.cpp:147-184)"""
+    b, t, s = _fit_call(_lib.lib().glmmr_mcml_optim_sparse, (cov, data, eff_range, Z, X, y, family, link), u,
+                        start, [int(trace), int(mcnr)], sparse=(Ap, Ai), maxfun=maxfun)
+    return dict(beta=b, theta=t[:_npar_of(cov)], sigma=s)
+
+
+def mcml_simlik_sparse(cov, data, eff_range, Ap, Ai, Z, X, y, u, family, link, start, trace=0, maxfun=0):
+    """mcml_simlik_sparse(...)   (src/mcml_optim.cpp:210-239)"""
+    b, t, s = _fit_call(_lib.lib().glmmr_mcml_simlik_sparse, (cov, data, eff_range, Z, X, y, family, link), u,
+                        start, [int(trace)], sparse=(Ap, Ai), maxfun=maxfun)
+    return dict(beta=b, theta=t[:_npar_of(cov)], sigma=s)
+
+
+def mcml_hess(cov, data, eff_range, Z, X, y, u, family, link, start, tol=1e-5, trace=0, sparse=None):
+    """mcml_hess(...) -> (P+R) x (P+R)   (src/mcml_optim.cpp:263-285; _sparse :313-337)"""
+    p, keep = _problem(cov, data, eff_range, Z, X, y, family, link)
+    u = _f(u); start = _f(start).ravel()
+    nv = p.P + _npar_of(cov)
+    H = np.zeros((nv, nv), order="F")
+    e = Ext(0, 1, 0, 0)
+    if sparse is None:
+        _lib.check(_lib.lib().glmmr_mcml_hess(C.byref(p), _p(u), u.shape[1], _p(start), start.size,
+                                              C.c_double(tol), int(trace), C.byref(e), _p(H)))
+    else:
+        Ap, Ai = _i(sparse[0]).ravel(), _i(sparse[1]).ravel()
+        _lib.check(_lib.lib().glmmr_mcml_hess_sparse(C.byref(p), Ap.ctypes.data_as(c_ip), Ai.ctypes.data_as(c_ip),
+                                                     Ai.size, _p(u), u.shape[1], _p(start), start.size,
+                                                     C.c_double(tol), int(trace), C.byref(e), _p(H)))
+    return H
+
+
+def mcml_hess_sparse(cov, data, eff_range, Ap, Ai, Z, X, y, u, family, link, start, tol=1e-5, trace=0):
+    return mcml_hess(cov, data, eff_range, Z, X, y, u, family, link, start, tol, trace, sparse=(Ap, Ai))
+
+
+def aic_mcml(cov, data, eff_range, Z, X, y, u, family, link, beta_par, cov_par):
+    """aic_mcml(...) -> double   (src/mcml_optim.cpp:356-392)"""
+    p, keep = _problem(cov, data, eff_range, Z, X, y, family, link)
+    u = _f(u); bp = _f(beta_par).ravel(); cp = _f(cov_par).ravel()
+    out = C.c_double(); e = Ext(0, 1, 0, 0)
+    _lib.check(_lib.lib().glmmr_mcml_aic(C.byref(p), _p(u), u.shape[1], _p(bp), bp.size, _p(cp), cp.size,
+                                         C.byref(e), C.byref(out)))
+    return out.value
+
+
+
 def mvn_ll(cov, data, eff_range, gamma, u):
     """mvn_ll(cov, data, eff_range, gamma, u)  -- src/mcml_optim.cpp:406-414"""
     cov = _i(cov); data = _f(data).ravel(); eff = _f(eff_range).ravel(); gamma = _f(gamma).ravel()

@@ -298,6 +298,17 @@ extern "C" int glmmr_mcml_sample_cols(int m, int chains)
     return chains * ((m + chains - 1) / chains);
 }
 
+// kernel timing (HIP events on the context's stream).  out: [fwd_ms, fwd_count, bwd_ms, bwd_count]
+extern "C" int glmmr_mcml_ctx_profile(glmmr_mcml_ctx* h, int enable, int reset, double* out4)
+{
+    MCML_REQUIRE(h, "profile: null context");
+    KernelProf& p = h->c.prof;
+    if (out4) { out4[0] = p.ms[0]; out4[1] = (double)p.cnt[0]; out4[2] = p.ms[1]; out4[3] = (double)p.cnt[1]; }
+    if (reset) for (int i = 0; i < 4; ++i) { p.ms[i] = 0; p.cnt[i] = 0; }
+    p.on = enable != 0;
+    return MCML_OK;
+}
+
 extern "C" int glmmr_mcml_ctx_ncols(glmmr_mcml_ctx* h) { return h ? h->c.mcols : 0; }
 extern "C" int glmmr_mcml_ctx_npar(glmmr_mcml_ctx* h) { return h ? h->c.cov.npar : 0; }
 

@@ -24,6 +24,36 @@ struct HmcState {
     int partial_slots = 0;
 };
 
+// HIP-event timing of the dominant kernels, on the stream they are launched on
+// (bench.py's roofline line).  kind 0 = HMC forward GEMM, 1 = HMC backward GEMM.
+struct KernelProf {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> kind;
+    size_t used = 0;
+    double ms[4] = {0, 0, 0, 0};
+    long long cnt[4] = {0, 0, 0, 0};
+    int begin(hipStream_t s, int k) {
+        if (!on) return -1;
+        if (2 * used + 1 >= ev.size()) {
+            for (int i = 0; i < 512; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return -1; ev.push_back(e); }
+            kind.resize(ev.size() / 2);
+        }
+        kind[used] = k;
+        (void)hipEventRecord(ev[2 * used], s);
+        return (int)used++;
+    }
+    void end(hipStream_t s, int slot) { if (slot >= 0) (void)hipEventRecord(ev[2 * slot + 1], s); }
+    void collect() {       // call after the stream has been synchronised
+        for (size_t i = 0; i < used; ++i) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) == hipSuccess) { ms[kind[i]] += t; cnt[kind[i]] += 1; }
+        }
+        used = 0;
+    }
+    ~KernelProf() { for (auto e : ev) (void)hipEventDestroy(e); }
+};
+
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -62,6 +92,7 @@ struct Ctx {
 
     // sampler
     HmcState hmc;
+    KernelProf prof;
 
     // distribution
     int rank = 0, world = 1;

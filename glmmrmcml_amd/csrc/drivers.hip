@@ -42,10 +42,15 @@ static int eval_loglik(Ctx& c, const double* beta, double var_par, double* ll)
     return MCML_OK;
 }
 
+// A theta at which some block is not positive definite has no likelihood: the
+// reference would return NaN from its unchecked Cholesky; the optimiser is told
+// "infinitely bad" so that it backs away instead of aborting the fit.
 static int eval_mvn(Ctx& c, const double* theta, double* logl)
 {
     double s = 0;
-    MCML_TRY(mvn_loglik_sum(c, theta, &s));
+    int rc = mvn_loglik_sum(c, theta, &s);
+    if (rc == MCML_ENOTPD) { *logl = -HUGE_VAL; return MCML_OK; }
+    MCML_TRY(rc);
     double tot[2] = {s, (double)c.mcols};
     MCML_TRY(allreduce_host(c, tot, 2));
     *logl = tot[0] / tot[1];

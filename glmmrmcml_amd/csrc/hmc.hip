@@ -281,7 +281,10 @@ static int hmc_forward(Ctx& c, const double* X, int ldx)
 {
     HmcState& h = c.hmc;
     EpiForward epi{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink};
-    return launch_gemm<false>(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
+    const int slot = c.prof.begin(c.stream, 0);
+    int rc = launch_gemm<false>(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
+    c.prof.end(c.stream, slot);
+    return rc;
 }
 
 static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_par, int mode)
@@ -289,7 +292,10 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
     HmcState& h = c.hmc;
     ChainArrays ca = chain_arrays(h);
     EpiBackward epi{Xs, G, h.R.d(), h.UP.d(), h.V.ld, ca.e, ca.steps, s, glm_score_post(var_par, c.flink), mode};
-    return launch_gemm<false>(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
+    const int slot = c.prof.begin(c.stream, 1);
+    int rc = launch_gemm<false>(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
+    c.prof.end(c.stream, slot);
+    return rc;
 }
 
 // log_prob and log_grad of every column of the current V
@@ -393,6 +399,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
     hipLaunchKernelGGL(k_hmc_diag, dim3(1), dim3(64), 0, c.stream, ca, C, c.scalars.d() + 8);
     MCML_HIP(hipMemcpyAsync(dg, c.scalars.d() + 8, sizeof dg, hipMemcpyDeviceToHost, c.stream));
     MCML_HIP(hipStreamSynchronize(c.stream));
+    c.prof.collect();
     if (diag) {
         diag->accept_rate = dg[0] / ((double)C * total);
         diag->mean_e = dg[1] / C; diag->min_e = dg[2]; diag->max_e = dg[3];

@@ -122,6 +122,19 @@ public:
             double rng = up_[i] - lo_[i];
             if (std::isfinite(rng)) { if (!(rng > 0)) { set_error("bobyqa: empty bound interval"); return MCML_EINVAL; } rhobeg = std::min(rhobeg, 0.5 * rng * 0.999); }
         }
+        // BOBYQA moves a start that is closer than rhobeg to a bound onto that bound.  For the
+        // covariance parameters (lower bound 1e-6, mcmloptim.h:35-38) that means evaluating the
+        // MVN likelihood at a variance of 1e-12: an objective ~1e11 that wrecks the first models.
+        // When no rhobeg was asked for, keep an interior start interior instead: the default is
+        // also capped by half the distance to the nearest bound.
+        if (!(o_.rhobeg > 0)) {
+            for (int i = 0; i < n; ++i) {
+                const double xi = std::min(std::max(x0_[i], lo_[i]), up_[i]);
+                const double dl = xi - lo_[i], du = up_[i] - xi;
+                if (std::isfinite(dl) && dl > 0) rhobeg = std::min(rhobeg, 0.5 * dl);
+                if (std::isfinite(du) && du > 0) rhobeg = std::min(rhobeg, 0.5 * du);
+            }
+        }
         const double rhoend = o_.rhoend > 0 ? std::min(o_.rhoend, rhobeg) : 1e-6 * rhobeg;
         // x0 is moved so that every coordinate is either on a bound or >= rhobeg from it (BOBYQA)
         vec x = x0_;
@@ -161,6 +174,7 @@ public:
                 double crvmin = 0;
                 d = trust_step(q_, delta, a, b, &crvmin);
                 dnorm = std::min(delta, norm2(d));
+                if (o_.iprint > 1) fprintf(stderr, "bobyqa tr: dnorm=%.3g delta=%.3g rho=%.3g crvmin=%.3g |g|=%.3g\n", dnorm, delta, rho, crvmin, norm2(q_.g));
                 if (dnorm < 0.5 * rho) {
                     ntrits = -1;
                     distsq = 100.0 * rho * rho;
@@ -204,6 +218,7 @@ public:
                 }
                 if (knew >= 0) {
                     const double dist = std::sqrt(dmax);
+                    if (o_.iprint > 1) fprintf(stderr, "bobyqa geom: replace %d dist=%.3g ntrits=%d delta=%.3g rho=%.3g\n", knew, dist, ntrits, delta, rho);
                     if (ntrits == -1) { delta = std::min(0.1 * delta, 0.5 * dist); if (delta <= 1.5 * rho) delta = rho; }
                     ntrits = 0;
                     const double adelt = std::max(std::min(0.1 * dist, delta), rho);
@@ -442,7 +457,9 @@ int bobyqa(const objective_fn& f, const std::vector<double>& x0, const std::vect
         res->x.assign(1, r2.x[0]); res->nfev = r2.nfev; res->status = r2.status;
         return f(res->x, &res->fval);
     }
-    Bobyqa b(f, x0, lower, upper, opts);
+    BobyqaOpts o = opts;
+    if (const char* t = getenv("GLMMR_MCML_BOBYQA_TRACE")) o.iprint = atoi(t);
+    Bobyqa b(f, x0, lower, upper, o);
     return b.run(res);
 }
 

@@ -138,6 +138,9 @@ typedef struct glmmr_mcml_ext {
  * (mhmcmc.h:126), chains * ceil(m / chains) otherwise */
 int glmmr_mcml_sample_cols(int m, int chains);
 int glmmr_mcml_ctx_ncols(glmmr_mcml_ctx* ctx);
+/* HIP-event timing of the sampler's two GEMMs on the context's stream.
+ * out4 (nullable) = [forward ms, forward launches, backward ms, backward launches] so far */
+int glmmr_mcml_ctx_profile(glmmr_mcml_ctx* ctx, int enable, int reset, double* out4);
 int glmmr_mcml_ctx_npar(glmmr_mcml_ctx* ctx);
 
 /* The same drivers on a resident context (what bench.py times). */

@@ -1,0 +1,132 @@
+"""GPU parity of the step exports (A10/A11): mcml_optim, mcml_simlik, mcml_hess, aic_mcml,
+mcmc_sample, mcml_full through the C ABI vs the oracle drivers on the same inputs.
+
+Tolerances: beta / theta / simulated log-likelihood 1e-6 relative (the north star's
+figure); aic 1e-9; Hessian entries 1e-4 relative to the largest entry (central differences
+with step 1e-5 amplify 1e-12 objective noise by 1e-2)."""
+import numpy as np
+import pytest
+
+from glmmrmcml_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _u(orc, d, m, seed=0, scale=1.0):
+    rng = np.random.default_rng(seed)
+    L = orc.gen_D(d["cov"], d["data"], d["eff_range"], d["theta"], chol=True)
+    return np.asfortranarray(L @ rng.normal(size=(d["Q"], m)) * scale)
+
+
+def _args(d):
+    return (d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"])
+
+
+CASES = [(synth.geospatial, dict(n=120), False), (synth.geospatial, dict(n=120), True),
+         (synth.cluster_rct, dict(ncl=8, nt=4, nind=6), False),
+         (synth.cluster_rct, dict(ncl=8, nt=4, nind=6, family="poisson"), True),
+         (synth.stepped_wedge, dict(ncl=10, nt=4, nind=5), True)]
+
+
+@pytest.mark.parametrize("gen,kw,mcnr", CASES)
+def test_mcml_optim(orc, gen, kw, mcnr):
+    from glmmrmcml_amd import api
+    from oracle import drivers
+    d = gen(**kw)
+    u = _u(orc, d, 40, seed=1)
+    mod = drivers.Model(*_args(d), d["family"], d["link"])
+    want = drivers.mcml_optim(mod, u, d["start"], mcnr=mcnr)
+    got = api.mcml_optim(*_args(d), u, d["family"], d["link"], d["start"], trace=0, mcnr=mcnr)
+    assert np.abs(got["beta"] - want["beta"]).max() < 1e-6 * max(1.0, np.abs(want["beta"]).max())
+    assert np.abs(got["theta"] - want["theta"]).max() < 1e-6 * max(1e-2, np.abs(want["theta"]).max()) * 5
+    if d["family"] == "gaussian":
+        assert abs(got["sigma"] - want["sigma"]) < 1e-6 * want["sigma"] * 5
+    # the objective value at the product's optimum is no worse than the oracle's
+    f = mod.D_obj(u)
+    assert f(got["theta"]) <= f(want["theta"]) + 1e-9 * abs(f(want["theta"]))
+
+
+def test_simlik_hess_aic(orc):
+    from glmmrmcml_amd import api
+    from oracle import drivers
+    d = synth.cluster_rct(ncl=8, nt=3, nind=8, seed=5)
+    u = _u(orc, d, 30, seed=2)
+    mod = drivers.Model(*_args(d), d["family"], d["link"])
+    got = api.mcml_simlik(*_args(d), u, d["family"], d["link"], d["start"])
+    want = drivers.mcml_simlik(mod, u, d["start"])
+    assert np.abs(got["beta"] - want["beta"]).max() < 1e-5 * max(1.0, np.abs(want["beta"]).max())
+    assert np.abs(got["theta"] - want["theta"]).max() < 1e-5
+    F = mod.F_obj(u, 30, 0.0)
+    fg, fw = F(np.r_[got["beta"], got["theta"]]), F(np.r_[want["beta"], want["theta"]])
+    assert abs(fg - fw) < 1e-6 * abs(fw)          # simulated log-likelihood at the optimum
+    start = np.r_[want["beta"], want["theta"], 1.0]
+    H = api.mcml_hess(*_args(d), u, d["family"], d["link"], start, tol=1e-4)
+    Ho = drivers.mcml_hess(mod, u, start, tol=1e-4)
+    assert np.abs(H - Ho).max() < 1e-4 * np.abs(Ho).max()
+    assert np.array_equal(H, H.T)
+    a = api.aic_mcml(*_args(d), u, d["family"], d["link"], want["beta"], want["theta"])
+    ao = drivers.aic_mcml(mod, u, want["beta"], want["theta"])
+    assert abs(a - ao) < 1e-9 * abs(ao)
+
+
+def test_gaussian_aic_and_hess_with_sigma(orc):
+    from glmmrmcml_amd import api
+    from oracle import drivers
+    d = synth.geospatial(90, seed=7)
+    u = _u(orc, d, 25, seed=3)
+    mod = drivers.Model(*_args(d), d["family"], d["link"])
+    bp = np.r_[d["beta"], d["sigma"]]
+    a = api.aic_mcml(*_args(d), u, d["family"], d["link"], bp, d["theta"])
+    assert abs(a - drivers.aic_mcml(mod, u, bp, d["theta"])) < 1e-9 * abs(a)
+    H = api.mcml_hess(*_args(d), u, d["family"], d["link"], d["start"], tol=1e-4)
+    Ho = drivers.mcml_hess(mod, u, d["start"], tol=1e-4)
+    assert np.abs(H - Ho).max() < 1e-4 * np.abs(Ho).max()
+
+
+def test_sparse_exports_use_the_block_path(orc):
+    from glmmrmcml_amd import api, _lib
+    from scipy import sparse
+    d = synth.stepped_wedge(ncl=6, nt=4, nind=4, seed=2)
+    u = _u(orc, d, 20, seed=4)
+    D = sparse.csc_matrix(np.triu(orc.gen_D(d["cov"], d["data"], d["eff_range"], d["theta"])))
+    dense = api.mcml_optim(*_args(d), u, d["family"], d["link"], d["start"], mcnr=True)
+    sp = api.mcml_optim_sparse(d["cov"], d["data"], d["eff_range"], D.indptr, D.indices, d["Z"], d["X"], d["y"], u,
+                               d["family"], d["link"], d["start"], mcnr=True)
+    assert np.array_equal(dense["beta"], sp["beta"]) and np.array_equal(dense["theta"], sp["theta"])
+    bad = D.indices.copy(); bad[-1] = 0          # an entry outside the blocks
+    with pytest.raises(_lib.McmlError):
+        api.mcml_optim_sparse(d["cov"], d["data"], d["eff_range"], D.indptr, bad, d["Z"], d["X"], d["y"], u,
+                              d["family"], d["link"], d["start"], mcnr=True)
+
+
+def test_mcmc_sample_export(orc):
+    from glmmrmcml_amd import api
+    d = synth.cluster_rct(ncl=5, nt=3, nind=4, seed=9)
+    L = orc.gen_D(d["cov"], d["data"], d["eff_range"], d["theta"], chol=True)
+    out = api.mcmc_sample(d["Z"], L, d["X"], d["y"], d["beta"], d["family"], d["link"], 10, 12, 0.3,
+                          maxsteps=6, seed=99)
+    assert out.shape == (d["Q"], 13)
+    so, _, _, _ = orc.hmc_chain(d["X"] @ d["beta"], d["Z"] @ L, d["y"], 1.0, 3, 10, 12, 0.3, 6, 0.9, 99)
+    assert np.abs(out - L @ so).max() < 1e-8
+
+
+@pytest.mark.parametrize("chains,mcnr", [(1, True), (8, True), (8, False)])
+def test_mcml_full_iteration_by_iteration(orc, chains, mcnr):
+    """two MCML iterations: the product's loop vs the oracle's sampler + step drivers"""
+    from glmmrmcml_amd import api
+    from oracle import drivers
+    d = synth.cluster_rct(ncl=8, nt=3, nind=6, seed=3)
+    mod = drivers.Model(*_args(d), d["family"], d["link"])
+    m, warm, lam, ms, ta, seed = 24, 20, 0.3, 8, 0.9, 4242
+    got = api.mcml_full(*_args(d), d["family"], d["link"], d["start"], mcnr=mcnr, m=m, maxiter=2, warmup=warm,
+                        tol=1e-12, verbose=False, lambda_=lam, maxsteps=ms, target_accept=ta, seed=seed,
+                        chains=chains)
+    beta, theta, sig = d["start"][:mod.P].copy(), d["start"][mod.P:mod.P + mod.R].copy(), 1.0
+    for it in (1, 2):
+        u, niter = drivers.sample(mod, beta, theta, sig, warm, m, lam, ms, ta, seed, it, chains)
+        r = drivers.mcml_optim(mod, u, np.r_[beta, theta, 1.0], mcnr=mcnr, niter=niter)
+        beta, theta = r["beta"], r["theta"]
+    assert not got["converged"]
+    assert np.abs(got["beta"] - beta).max() < 2e-6 * max(1.0, np.abs(beta).max())
+    assert np.abs(got["theta"] - theta).max() < 2e-6
+    assert np.abs(got["u"] - u).max() < 1e-6

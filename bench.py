@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+
+metric : MCML iters/sec x m chains (simlik evals/sec)
+step   : one MCML iteration = one pass of the `while` body of mcml_full
+         (src/mcml_full.cpp:83-140): draw the samples (HMC) + beta-step (MCNR) +
+         theta-step (BOBYQA on the MVN log-likelihood) + L refresh.
+workload (every N): Gaussian geospatial, n = Q = 5000, ~(1|fexp(x,y)), dense Sigma,
+         m = 1024 chains PER GPU (weak scaling: chains shard over ranks, ZL/X/y/L
+         replicated, one RCCL all-reduce of the statistics per evaluation),
+         HMC warmup 100 + 1 draw per chain, 10 leapfrog steps, theta-step budget 40
+         objective evaluations.  Synthetic data, seed 20240601.
+Inputs are resident in HBM before the timed region starts.
+
+Launch: python bench.py --gpus 1 --steps K --warmup W      (single GPU)
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix, vendor figure (SURVEY.md 8d / BASELINE.md)
+
+CFG = dict(n=5000, chains_per_gpu=1024, hmc_warmup=100, max_steps=10, lambda_=5.0, target_accept=0.9,
+           theta_maxfun=40, seed=20240601)
+
+
+def cpu_baseline(d, cfg, budget_props=30):
+    """The CPU path timed on this box's host cores on a BOUNDED sample, extrapolated to one MCML
+    iteration with the reference's own operation counts.  Checker code only (oracle/ + numpy)."""
+    import scipy.linalg as sla
+    from oracle import oracle as orc
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:                                   # pragma: no cover
+        threadpool_limits = None
+    threads = orc.num_threads()
+    n = cfg["n"]; m = cfg["chains_per_gpu"]; W = cfg["hmc_warmup"]; E = cfg["theta_maxfun"]
+    ctxmgr = threadpool_limits(limits=threads) if threadpool_limits else None
+    if ctxmgr is not None:
+        ctxmgr.__enter__()
+    try:
+        t0 = time.time(); D = orc.gen_D(d["cov"], d["data"], d["eff_range"], d["theta"]); t_build = time.time() - t0
+        t0 = time.time(); L = np.linalg.cholesky(D); t_chol = time.time() - t0          # Eigen LLT's job
+        rng = np.random.default_rng(1)
+        ucol = L @ rng.standard_normal(n)
+        t0 = time.time(); sla.solve_triangular(L, ucol, lower=True); t_fsub = time.time() - t0
+        U = np.asfortranarray(L @ rng.standard_normal((n, 64)))
+        t0 = time.time(); sla.solve_triangular(L, U, lower=True); t_trsm64 = time.time() - t0
+        t0 = time.time(); ZU = d["Z"] @ U; t_zu64 = time.time() - t0                    # Z*u, 64 columns
+        ZL = np.asfortranarray(L)                                                        # Z = I
+        xb = d["X"] @ d["beta"]
+        t0 = time.time()
+        orc.hmc_chain(xb, ZL, d["y"], d["sigma"], 7, budget_props - 1, 1, cfg["lambda_"], cfg["max_steps"],
+                      cfg["target_accept"], cfg["seed"])
+        t_prop = (time.time() - t0) / budget_props
+    finally:
+        if ctxmgr is not None:
+            ctxmgr.__exit__(None, None, None)
+    t_zu = t_zu64 * m / 64.0
+    t_refresh = t_build + t_chol + t_zu64 * n / 64.0                                     # genD + Z*L
+    # reference-faithful (what mcml_full does): one sequential chain of W + m proposals
+    # (mhmcmc.h:121-157); MCNR re-multiplies Z*u once per sample (mcmlmodel.h:121, defect D3);
+    # every theta evaluation rebuilds + refactorises the block once per column (mcmldmatrix.h:59, D2)
+    t_faithful = (W + m) * t_prop + m * t_zu + E * (m + 1) * (t_build + t_chol + t_fsub) + t_refresh
+    # algorithmically fair: factor once per theta, Z*u cached
+    t_fair = (W + m) * t_prop + t_zu + E * (t_build + t_chol + t_trsm64 * (m + 1) / 64.0) + t_refresh
+    return {
+        "value": m / t_faithful, "unit": "simlik evals/s", "cores": int(threads), "kind": "port",
+        "value_fair": m / t_fair,
+        "sample": ("oracle C restatement (OpenMP) + numpy/LAPACK standing in for Eigen, %d threads; timed: %d HMC "
+                   "proposals at n=Q=%d (%.3f s each), 1 covariance build (%.2f s), 1 Cholesky (%.2f s), 1 forward-sub "
+                   "(%.3f s), TRSM and Z*u on 64 columns; extrapolated to one MCML iteration = %d sequential proposals "
+                   "+ MCNR + %d theta evaluations + L refresh. value = reference-faithful (per-column refactorisation, "
+                   "Z*u per sample: %.3g s/iter); value_fair = factor once per theta, cached Z*u (%.3g s/iter)"
+                   % (threads, budget_props, n, t_prop, t_build, t_chol, t_fsub, W + m, E, t_faithful, t_fair)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--n", type=int, default=CFG["n"], help="override n = Q (debug only; invalidates the metric)")
+    ap.add_argument("--chains", type=int, default=CFG["chains_per_gpu"])
+    args = ap.parse_args()
+
+    import torch
+    from glmmrmcml_amd import api, dist as gdist, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    hook = None
+    if world > 1:
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        hook = gdist.make_reduce_hook()
+
+    cfg = dict(CFG); cfg["n"] = args.n; cfg["chains_per_gpu"] = args.chains
+    n, C = cfg["n"], cfg["chains_per_gpu"]
+    d = synth.geospatial(n, seed=cfg["seed"])
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"],
+                      device=local_rank, stream=stream, rank=rank, world=world, reduce=hook)
+
+    def run(iters):
+        return ctx.mcml_full(d["start"], mcnr=True, m=C, maxiter=iters, warmup=cfg["hmc_warmup"], tol=0.0,
+                             verbose=False, lambda_=cfg["lambda_"], maxsteps=cfg["max_steps"],
+                             target_accept=cfg["target_accept"], seed=cfg["seed"], chains=C,
+                             maxfun=cfg["theta_maxfun"])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            tdist.barrier()
+            torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run(args.warmup)
+    ctx.profile(enable=True, reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    res = run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tdist.all_reduce(tt, op=tdist.ReduceOp.MAX)
+        dt = float(tt.item())
+    prof = ctx.profile(enable=False)
+    assert res["iters"] == args.steps, "timed region ran %d iterations, not %d" % (res["iters"], args.steps)
+
+    if rank == 0:
+        launches = prof["fwd_n"] + prof["bwd_n"]
+        avg_s = (prof["fwd_ms"] + prof["bwd_ms"]) / max(1, launches) * 1e-3
+        flops = 2.0 * n * n * C                      # algorithmic flops of one n x Q x C product
+        achieved = flops / avg_s / 1e12 if launches else 0.0
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(pj) and n == CFG["n"] and C == CFG["chains_per_gpu"]:
+            try:
+                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "MCML iters/sec x m chains (simlik evals/sec)",
+            "value": args.steps * C * world / dt,
+            "unit": "simlik evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "gaussian geospatial n=Q=%d fexp dense Sigma, MCNR, m=%d chains per GPU "
+                                   "(HMC warmup %d + 1 draw/chain, %d leapfrog steps), theta-step BOBYQA budget %d evals"
+                                   % (n, C, cfg["hmc_warmup"], cfg["max_steps"], cfg["theta_maxfun"]),
+                       "n": n, "Q": n, "m_per_gpu": C, "m_total": C * world, "parallelism": "chains x%d" % world,
+                       "accept_rate": res["accept_rate"], "leapfrog_steps_last_iter": res["leapfrog_total"]},
+            "roofline": {"bound": "mfma", "kernel": "dgemm_mfma_kernel (HMC forward / backward n x Q x C product)",
+                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "launches": launches, "avg_launch_ms": avg_s * 1e3,
+                         "gemm_share_of_step": (prof["fwd_ms"] + prof["bwd_ms"]) * 1e-3 / dt},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(d, cfg)
+            except Exception as e:           # the baseline never blocks the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "simlik evals/s", "cores": 0, "kind": "port",
+                                        "sample": "failed: %r" % (e,)}
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+"""Chain sharding over the GPUs of one node.
+
+One process per GPU.  Independent HMC chains / sample columns shard naturally:
+rank r owns global chains [r*C, (r+1)*C); ZL, X, y and L are replicated; the RNG
+streams are keyed by the GLOBAL chain id, so a chain's draws do not depend on
+how many ranks there are.  The only exchange is an all-reduce (sum, f64) of the
+per-chain sufficient statistics: P*P + P + 2 doubles for the MCNR beta-step and
+2 doubles (sum, count) per objective evaluation of the MCEM / theta steps.  The
+payload is tiny (latency-bound), so it is ONE collective per evaluation on the
+stream the kernels run on.  torch.distributed's "nccl" backend is RCCL on ROCm
+and runs over xGMI between the GPUs of a node.
+"""
+import ctypes as C
+
+import numpy as np
+
+
+def shard(total, world, rank):
+    """[lo, hi) of `total` units for `rank` of `world`: contiguous, sizes differ by <= 1"""
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def chain_offset(chains_per_rank, rank):
+    return int(chains_per_rank) * int(rank)
+
+
+def combine_mcnr(stats_list, P):
+    """what the all-reduce of the MCNR statistics computes, on host arrays:
+    stats = [sum X'W_iX (P*P) | sum X'W_i d_i r_i (P) | sum sigma_i | count]"""
+    tot = np.sum(np.asarray(stats_list, dtype=float), axis=0)
+    m = tot[P * P + P + 1]
+    XtWX = tot[:P * P].reshape(P, P, order="F") / m
+    XtWr = tot[P * P:P * P + P] / m
+    return np.linalg.solve(XtWX, XtWr), tot[P * P + P] / m
+
+
+class _DevArray:
+    """a raw device pointer as a __cuda_array_interface__ producer (no copy)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def make_reduce_hook(group=None):
+    """reduce hook for glmmr_mcml_dev_opts: sums `n` doubles at a device pointer over the
+    process group, in place, with torch.distributed (backend nccl = RCCL over xGMI)."""
+    import torch
+    import torch.distributed as dist
+
+    def hook(user, ptr, n):
+        try:
+            t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.current_stream().synchronize()
+            return 0
+        except Exception as e:        # never let an exception cross the C boundary
+            print("glmmrmcml_amd.dist: reduce hook failed:", e, flush=True)
+            return 1
+    return hook

@@ -21,6 +21,15 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+void orc_set_num_threads(int t)
+{
+#ifdef _OPENMP
+    if (t > 0) omp_set_num_threads(t);
+#else
+    (void)t;
+#endif
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -104,6 +104,7 @@ int orc_mcnr(int n, int Q, int P, int m, const double *X, const double *Z, const
              double *beta_out, double *sigma_out);
 
 int orc_num_threads(void);
+void orc_set_num_threads(int t);
 
 #ifdef __cplusplus
 }

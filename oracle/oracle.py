@@ -88,6 +88,9 @@ def lib():
                                c_dp, C.c_double, C.c_int, C.c_int, C.c_int,
                                c_dp, c_dp, c_dp, c_dp, c_dp]
         L.orc_gemm_nn.argtypes = [C.c_int, C.c_int, C.c_int, c_dp, C.c_int, c_dp, C.c_int, c_dp, C.c_int]
+        # libgomp may have been initialised (by torch / numpy) before the environment variables
+        # above were set: bound the team explicitly as well
+        L.orc_set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "16")))
         _LIB = L
     return _LIB
 

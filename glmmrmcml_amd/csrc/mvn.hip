@@ -164,6 +164,39 @@ __global__ __launch_bounds__(256) void k_build_dense(double* A, int lda, int bid
     if (mirror && i != j) A[j + (size_t)i * lda] = v;
 }
 
+// broadcast lane `src` (compile-time constant) of a double: two v_readlane_b32, no LDS round trip
+template <int SRC>
+__device__ __forceinline__ double bcast_lane(double v)
+{
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], SRC);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], SRC);
+    return u.d;
+}
+
+template <int C, int J>
+__device__ __forceinline__ void potrf16_upd(double (&a)[16], double l, int r)
+{
+    const double lj = bcast_lane<J>(l);
+    if (r >= J) a[J] -= l * lj;
+    if constexpr (J < 15) potrf16_upd<C, J + 1>(a, l, r);
+}
+
+template <int C>
+__device__ __forceinline__ void potrf16_col(double (&a)[16], int r, int lane, int* errflag)
+{
+    double diag = bcast_lane<C>(a[C]);
+    if (!(diag > 0.0)) { if (lane == 0) atomicExch(errflag, 1); diag = 1.0; }
+    const double d = sqrt(diag);
+    const double l = (r == C) ? d : a[C] / d;
+    a[C] = l;
+    if constexpr (C < 15) {
+        // a[j] -= l * l_j for j > C, l_j = lane j's l
+        potrf16_upd<C, C + 1>(a, l, r);
+    }
+}
+
 // Leaf of the recursive factorisation: n <= 128.  One workgroup keeps the
 // block in LDS (row stride 129: conflict-free column walks), factorises it in
 // 16-wide panels (the 16x16 diagonal tile in registers via wave shuffles), then
@@ -174,12 +207,23 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, d
     extern __shared__ __attribute__((aligned(16))) double S[];
     constexpr int LS = 129;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < n * n; e += 256) {
-        int i = e % n, j = e / n;
-        S[i * LS + j] = (i >= j) ? A[i + (size_t)j * lda] : 0.0;
+    {   // load the lower triangle: thread = (row, column parity); 16 loads in flight per thread
+        const int i = tid & 127, j0 = tid >> 7;
+        for (int jb = 0; jb < 128; jb += 32) {
+            double v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int j = jb + j0 + 2 * q;
+                v[q] = (i < n && j < n && i >= j) ? A[i + (size_t)j * lda] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) S[i * LS + jb + j0 + 2 * q] = v[q];
+        }
     }
     __syncthreads();
-    for (int kb = 0; kb < n; kb += 16) {
+    const int ntile = (n + 15) >> 4;
+    for (int kt = 0; kt < ntile; ++kt) {
+        const int kb = kt * 16;
         if (wave == 0) {
             // (a) 16x16 diagonal tile, one row per lane (lanes >= 16 mirror lane&15)
             const int r = lane & 15;
@@ -187,19 +231,14 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, d
 #pragma unroll
             for (int c = 0; c < 16; ++c)
                 a[c] = (kb + r < n && kb + c < n) ? S[(kb + r) * LS + kb + c] : (r == c ? 1.0 : 0.0);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                double diag = __shfl(a[c], c);
-                if (!(diag > 0.0)) { if (lane == 0) atomicExch(errflag, 1); diag = 1.0; }
-                double d = sqrt(diag);
-                double l = (r == c) ? d : a[c] / d;
-                a[c] = l;
-#pragma unroll
-                for (int j = c + 1; j < 16; ++j) {
-                    double lj = __shfl(l, j);
-                    if (r >= j) a[j] -= l * lj;
-                }
-            }
+            potrf16_col<0>(a, r, lane, errflag);  potrf16_col<1>(a, r, lane, errflag);
+            potrf16_col<2>(a, r, lane, errflag);  potrf16_col<3>(a, r, lane, errflag);
+            potrf16_col<4>(a, r, lane, errflag);  potrf16_col<5>(a, r, lane, errflag);
+            potrf16_col<6>(a, r, lane, errflag);  potrf16_col<7>(a, r, lane, errflag);
+            potrf16_col<8>(a, r, lane, errflag);  potrf16_col<9>(a, r, lane, errflag);
+            potrf16_col<10>(a, r, lane, errflag); potrf16_col<11>(a, r, lane, errflag);
+            potrf16_col<12>(a, r, lane, errflag); potrf16_col<13>(a, r, lane, errflag);
+            potrf16_col<14>(a, r, lane, errflag); potrf16_col<15>(a, r, lane, errflag);
             if (lane < 16) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
@@ -207,54 +246,127 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, d
             }
         }
         __syncthreads();
-        // (b) panel below the tile: x L11^T = a, one row per thread
-        for (int i = kb + 16 + tid; i < n; i += 256) {
+        // (b) panel below the tile: x L11^T = a, one row per thread (rows padded to the tile grid
+        // are zero and stay zero)
+        for (int i = kb + 16 + tid; i < ntile * 16; i += 256) {
             double x[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 double s = S[i * LS + kb + c];
 #pragma unroll
                 for (int k = 0; k < c; ++k) s -= x[k] * S[(kb + c) * LS + kb + k];
-                x[c] = s / S[(kb + c) * LS + kb + c];
+                const double dg = S[(kb + c) * LS + kb + c];
+                x[c] = (kb + c < n) ? s / dg : 0.0;
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c) S[i * LS + kb + c] = x[c];
         }
         __syncthreads();
-        // (c) trailing update of the lower triangle
-        const int t0 = kb + 16, T = n - t0;
-        for (int e = tid; e < T * T; e += 256) {
-            int i = e / T, j = e - i * T;
-            if (j <= i) {
-                double s = 0;
+        // (c) trailing update of the lower tiles on the matrix cores: C -= P P^T, K = 16
+        const int t0 = kt + 1, nrem = ntile - t0;
+        const int ntri = nrem * (nrem + 1) / 2;
+        for (int t = wave; t < ntri; t += 4) {
+            int ti = 0, rem = t;                       // t -> (ti >= tj) in row-major triangle order
+            while (rem > ti) { rem -= ti + 1; ++ti; }
+            const int tj = rem;
+            const int ri = (t0 + ti) * 16, rj = (t0 + tj) * 16;
+            d4 acc;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) s += S[(t0 + i) * LS + kb + c] * S[(t0 + j) * LS + kb + c];
-                S[(t0 + i) * LS + t0 + j] -= s;
+            for (int r = 0; r < 4; ++r) acc[r] = S[(ri + (lane >> 4) + 4 * r) * LS + rj + (lane & 15)];
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const double pa = -S[(ri + (lane & 15)) * LS + kb + kc * 4 + (lane >> 4)];
+                const double pb = S[(rj + (lane & 15)) * LS + kb + kc * 4 + (lane >> 4)];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(ri + (lane >> 4) + 4 * r) * LS + rj + (lane & 15)] = acc[r];
+        }
+        __syncthreads();
+    }
+    {   // write L
+        const int i = tid & 127, j0 = tid >> 7;
+        if (i < n)
+            for (int j = j0; j <= i && j < n; j += 2) A[i + (size_t)j * lda] = S[i * LS + j];
+    }
+    // ---- inverse X = inv(L), 16 x 16 tiles; X[i][j] (i > j) is kept at S[j][i] (the unused
+    // upper triangle), its diagonal in xd ----
+    double* xd = S + 128 * LS;            // 128 doubles
+    double* Tt = xd + 128;                // 7 tiles of 16 x 16
+    const int nt = (n + 15) >> 4;
+    // (1) diagonal tiles: one thread per column, forward substitution in registers
+    if (tid < 128) {
+        const int I = tid >> 4, c = tid & 15, base = I * 16;
+        if (base + c < n) {
+            double x[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                double v = 0.0;
+                if (r == c) v = 1.0 / S[(base + r) * LS + base + r];
+                else if (r > c && base + r < n) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (k >= c && k < r) sacc += S[(base + r) * LS + base + k] * x[k];
+                    v = -sacc / S[(base + r) * LS + base + r];
+                }
+                x[r] = v;
+            }
+            xd[base + c] = x[c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (r > c && base + r < n) S[(base + c) * LS + base + r] = x[r];
+        }
+    }
+    __syncthreads();
+    // (2) block rows: X_IJ = -X_II * sum_{K=J}^{I-1} L_IK X_KJ, the 16x16x16 tile products on
+    // the matrix cores (one (I, J) tile per wave at a time)
+    for (int I = 1; I < nt; ++I) {
+        for (int J = wave; J < I; J += 4) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            const int l15 = lane & 15, lk = lane >> 4;
+            for (int K = J; K < I; ++K) {
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const int t = kc * 4 + lk;
+                    // A operand: L_IK[row l15][t];  B operand: X_KJ[t][col l15]
+                    const double pa = S[(I * 16 + l15) * LS + K * 16 + t];
+                    double pb;
+                    if (K == J) pb = (t == l15) ? xd[J * 16 + l15] : (t > l15 ? S[(J * 16 + l15) * LS + J * 16 + t] : 0.0);
+                    else pb = S[(J * 16 + l15) * LS + K * 16 + t];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
+                }
+            }
+            // T_J[row][col]: row = lk + 4 r, col = l15
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Tt[J * 256 + (lk + 4 * r) * 16 + l15] = acc[r];
+        }
+        __syncthreads();
+        for (int J = wave; J < I; J += 4) {   // X_IJ = -X_II T_J
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            const int l15 = lane & 15, lk = lane >> 4;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const int t = kc * 4 + lk;
+                // A operand: X_II[row l15][t] (lower triangular);  B operand: T_J[t][col l15]
+                const double pa = (t == l15) ? xd[I * 16 + l15]
+                                             : (t < l15 ? S[(I * 16 + t) * LS + I * 16 + l15] : 0.0);
+                const double pb = Tt[J * 256 + t * 16 + l15];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = I * 16 + lk + 4 * r, gj = J * 16 + l15;
+                if (gi < n) S[gj * LS + gi] = -acc[r];
             }
         }
         __syncthreads();
     }
-    // write L
-    for (int e = tid; e < n * n; e += 256) {
-        int i = e % n, j = e / n;
-        if (i >= j) A[i + (size_t)j * lda] = S[i * LS + j];
-    }
-    // inverse: X = inv(L); column j by thread j; X[i][j] (i > j) kept at S[j][i]
-    if (tid < n) {
-        const int j = tid;
-        const double xjj = 1.0 / S[j * LS + j];
-        for (int i = j + 1; i < n; ++i) {
-            double s = S[i * LS + j] * xjj;
-            for (int k = j + 1; k < i; ++k) s += S[i * LS + k] * S[j * LS + k];
-            S[j * LS + i] = -s / S[i * LS + i];
-        }
-    }
-    __syncthreads();
     for (int e = tid; e < 128 * 128; e += 256) {
         int i = e & 127, j = e >> 7;
         double v = 0.0;
         if (i < n && j < n) {
-            if (i == j) v = 1.0 / S[j * LS + j];
+            if (i == j) v = xd[j];
             else if (i > j) v = S[j * LS + i];
         }
         Linv[i + j * 128] = v;
@@ -305,6 +417,9 @@ __global__ void k_zero_upper(double* A, int lda, int n)
     if (i < n && j < n && i < j) A[i + (size_t)j * lda] = 0.0;
 }
 
+// LDS of k_potrf_leaf: the 128 x 129 block, the inverse's diagonal, 7 scratch tiles
+static constexpr size_t POTRF_LDS = sizeof(double) * (128 * 129 + 128 + 7 * 256);
+
 // ------------------------------------------------------------------ recursion (host)
 static inline int split128(int n)
 {
@@ -338,7 +453,7 @@ static int potrf_rec(Ctx& c, double* A0, int lda, int off, int n)
     double* A = A0 + off + (size_t)off * lda;
     if (n <= CHOL_NB) {
         double* Linv = c.linv.d() + (size_t)(off / CHOL_NB) * CHOL_NB * CHOL_NB;
-        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), sizeof(double) * 128 * 129, c.stream,
+        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), POTRF_LDS, c.stream,
                            A, lda, n, Linv, c.scalars.as<int>() + 32);
         MCML_HIP(hipGetLastError());
         return MCML_OK;
@@ -353,6 +468,58 @@ static int potrf_rec(Ctx& c, double* A0, int lda, int off, int n)
     return potrf_rec(c, A0, lda, off + n1, n2);
 }
 
+// Right-looking variant: one 128-wide panel at a time -- leaf (factor + invert the diagonal
+// block in LDS), panel TRSM as a GEMM against the inverted block, SYRK of the whole
+// trailing matrix.  3 launches per panel instead of the recursion's many small ones.
+static bool chol_blocked()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GLMMR_MCML_CHOL"); v = (e && !strcmp(e, "rec")) ? 0 : 1; }
+    return v == 1;
+}
+
+static int potrf_blocked(Ctx& c, double* A, int lda, int n)
+{
+    for (int k = 0; k < n; k += CHOL_NB) {
+        const int nb = (n - k < CHOL_NB) ? n - k : CHOL_NB;
+        double* A11 = A + k + (size_t)k * lda;
+        double* Linv = c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB;
+        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), POTRF_LDS, c.stream, A11, lda, nb, Linv,
+                           c.scalars.as<int>() + 32);
+        MCML_HIP(hipGetLastError());
+        const int rem = n - k - nb;
+        if (rem <= 0) break;
+        double* A21 = A11 + nb;
+        {
+            EpiAxpby epi{A21, lda, 1.0, 0.0};
+            MCML_TRY(launch_gemm<true>(c.stream, rem, nb, nb, A21, lda, Linv, CHOL_NB, epi, false, 1));
+        }
+        double* A22 = A11 + nb + (size_t)nb * lda;
+        EpiAxpby epi{A22, lda, -1.0, 1.0};
+        MCML_TRY(launch_gemm<true>(c.stream, rem, rem, nb, A21, lda, A21, lda, epi, true));
+    }
+    return MCML_OK;
+}
+
+static int trsm_left_blocked(Ctx& c, const double* L, int ldl, int n, double* U, int ldu, int m)
+{
+    for (int k = 0; k < n; k += CHOL_NB) {
+        const int nb = (n - k < CHOL_NB) ? n - k : CHOL_NB;
+        const double* Linv = c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB;
+        double* Uk = U + k;
+        {
+            EpiAxpby epi{Uk, ldu, 1.0, 0.0};
+            MCML_TRY(launch_gemm<false>(c.stream, nb, m, nb, Linv, CHOL_NB, Uk, ldu, epi, false, 2));
+        }
+        const int rem = n - k - nb;
+        if (rem <= 0) break;
+        const double* L21 = L + (k + nb) + (size_t)k * ldl;
+        EpiAxpby epi{Uk + nb, ldu, -1.0, 1.0};
+        MCML_TRY(launch_gemm<false>(c.stream, rem, m, nb, L21, ldl, Uk, ldu, epi));
+    }
+    return MCML_OK;
+}
+
 int potrf_lower(Ctx& c, double* A, int n, int lda)
 {
     MCML_REQUIRE(n > 0 && lda >= n && (lda & 1) == 0, "potrf: bad shape n=%d lda=%d", n, lda);
@@ -360,9 +527,10 @@ int potrf_lower(Ctx& c, double* A, int n, int lda)
     static bool attr = false;
     if (!attr) {
         MCML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_leaf),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 128 * 129)));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_LDS));
         attr = true;
     }
+    if (chol_blocked()) return potrf_blocked(c, A, lda, n);
     return potrf_rec(c, A, lda, 0, n);
 }
 
@@ -386,6 +554,7 @@ static int trsm_left_rec(Ctx& c, const double* A0, int lda, int off, int n, doub
 
 int trsm_left_lower(Ctx& c, const double* L, int ldl, int n, double* U, int ldu, int m)
 {
+    if (chol_blocked()) return trsm_left_blocked(c, L, ldl, n, U, ldu, m);
     return trsm_left_rec(c, L, ldl, 0, n, U, ldu, m);
 }
 

@@ -26,7 +26,7 @@ def _gemm(A, B, Cm, alpha, beta, b_nmajor, lower_only=0, tile=-1):
 @pytest.mark.parametrize("M,N,K", [(16, 16, 4), (160, 128, 16), (161, 129, 17), (333, 77, 250),
                                    (1000, 256, 999), (5, 3, 2), (640, 512, 640)])
 @pytest.mark.parametrize("b_nmajor", [0, 1])
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_dgemm_matches_numpy(M, N, K, b_nmajor, tile):
     rng = np.random.default_rng(M * 7 + N * 3 + K)
     A = rng.normal(size=(M, K)); Bm = rng.normal(size=(K, N)); C0 = rng.normal(size=(M, N))

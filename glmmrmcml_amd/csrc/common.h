@@ -91,10 +91,12 @@ struct DevBuf {
 struct DevMat {
     DevBuf buf;
     int rows = 0, cols = 0, ld = 0;
-    int alloc(int r, int c) {
+    int cols_alloc = 0;     // columns actually allocated (>= cols; round_up(cols, col_align))
+    int alloc(int r, int c, int col_align = 1) {
         int nld = pad_ld(r);
-        MCML_TRY(buf.ensure(sizeof(double) * (size_t)nld * (size_t)(c < 1 ? 1 : c)));
-        rows = r; cols = c; ld = nld;
+        int ca = round_up(c < 1 ? 1 : c, col_align);
+        MCML_TRY(buf.ensure(sizeof(double) * (size_t)nld * (size_t)ca));
+        rows = r; cols = c; ld = nld; cols_alloc = ca;
         return MCML_OK;
     }
     double* d() const { return buf.d(); }

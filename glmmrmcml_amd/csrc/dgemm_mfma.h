@@ -83,7 +83,7 @@ struct EpiAxpby {   // C = alpha*A*B + beta*C
     }
 };
 
-template <int WTM, int WTN, int WM, int WN, bool BNMAJOR, int BK, bool STAGGER, class Epi>
+template <int WTM, int WTN, int WM, int WN, bool BNMAJOR, int BK, bool STAGGER, int INNER, class Epi>
 __global__ __launch_bounds__(64 * WM * WN) void dgemm_mfma_kernel(GemmP p, Epi epi)
 {
     using Cfg = GemmCfg<WTM, WTN, WM, WN, BNMAJOR, BK>;
@@ -215,19 +215,41 @@ __global__ __launch_bounds__(64 * WM * WN) void dgemm_mfma_kernel(GemmP p, Epi e
         const double* as = As + cur * Cfg::A_TILE + wr * 16 * WTM + l15;
         const double* bs = BNMAJOR ? (Bs + cur * Cfg::B_TILE + wc * 16 * WTN + l15)
                                    : (Bs + cur * Cfg::B_TILE + (wc * 16 * WTN + l15) * SB);
+        if constexpr (INNER == 2) {
+            // all fragments of the K step first (BK/4 * (WTM + WTN) doubles), then the MFMAs
+            double a[BK / 4][WTM], b[BK / 4][WTN];
 #pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks) {
-            const int kk = 4 * ks + lk;
-            double a[WTM], b[WTN];
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                const int kk = 4 * ks + lk;
 #pragma unroll
-            for (int i = 0; i < WTM; ++i) a[i] = as[kk * SA + 16 * i];
+                for (int i = 0; i < WTM; ++i) a[ks][i] = as[kk * SA + 16 * i];
 #pragma unroll
-            for (int j = 0; j < WTN; ++j) b[j] = BNMAJOR ? bs[kk * SB + 16 * j] : bs[16 * j * SB + kk];
+                for (int j = 0; j < WTN; ++j) b[ks][j] = BNMAJOR ? bs[kk * SB + 16 * j] : bs[16 * j * SB + kk];
+            }
 #pragma unroll
-            for (int i = 0; i < WTM; ++i)
+            for (int ks = 0; ks < BK / 4; ++ks)
 #pragma unroll
-                for (int j = 0; j < WTN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[ks][j], a[ks][i], acc[i][j], 0, 0, 0);
+        } else {
+            if constexpr (INNER == 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                const int kk = 4 * ks + lk;
+                double a[WTM], b[WTN];
+#pragma unroll
+                for (int i = 0; i < WTM; ++i) a[i] = as[kk * SA + 16 * i];
+#pragma unroll
+                for (int j = 0; j < WTN; ++j) b[j] = BNMAJOR ? bs[kk * SB + 16 * j] : bs[16 * j * SB + kk];
+#pragma unroll
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+            if constexpr (INNER == 1) __builtin_amdgcn_s_setprio(0);
         }
     };
 
@@ -284,12 +306,13 @@ __global__ __launch_bounds__(64 * WM * WN) void dgemm_mfma_kernel(GemmP p, Epi e
 // v_mfma_f64_16x16x4_f64 issues every 64 cycles from one wave (scripts/mfma_peak.hip: 77.4
 // TFLOP/s = 98.5 % of the 78.6 vendor peak with one wave per SIMD).
 struct TileChoice { int id; };
-static const struct { int bm, bn; double eff; } kTileTab[13] = {
+static const struct { int bm, bn; double eff; } kTileTab[16] = {
     {160, 128, 1.00}, {128, 128, 0.97}, {128, 64, 0.90}, {64, 64, 0.80},
     {160, 128, 0.50}, {128, 128, 0.50},    // 4, 5: the same tiles with 16 waves (not picked by default)
     {160, 128, 0.50}, {160, 128, 0.50},    // 6, 7: K step 32, 8 / 16 waves
     {160, 128, 0.50}, {160, 128, 0.50}, {128, 128, 0.50},    // 8, 9, 10: staggered SIMD partners
-    {160, 128, 0.50}, {160, 128, 0.50}};   // 11, 12: 4 waves (one per SIMD), 5x4 tiles per wave
+    {160, 128, 0.50}, {160, 128, 0.50},    // 11, 12: 4 waves (one per SIMD), 5x4 tiles per wave
+    {160, 128, 0.50}, {160, 128, 0.50}, {160, 128, 0.50}};   // 13-15: inner-loop variants (setprio, preload)
 
 // Smallest estimated time: workgroups are dealt 256 at a time (one per CU);
 // smaller tiles pay more staging per flop.  Only ids 0-3 and 6 are candidates; the others
@@ -311,7 +334,7 @@ static inline TileChoice pick_tile(int M, int N, int K = 1 << 30)
     return best;
 }
 
-template <int WTM, int WTN, int WM, int WN, bool BNMAJOR, int BK, bool STAGGER, class Epi>
+template <int WTM, int WTN, int WM, int WN, bool BNMAJOR, int BK, bool STAGGER, int INNER, class Epi>
 static inline int launch_gemm_tile(hipStream_t s, GemmP p, const Epi& epi)
 {
     using Cfg = GemmCfg<WTM, WTN, WM, WN, BNMAJOR, BK>;
@@ -320,11 +343,11 @@ static inline int launch_gemm_tile(hipStream_t s, GemmP p, const Epi& epi)
     static bool attr_set = false;
     if (!attr_set) {
         MCML_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&dgemm_mfma_kernel<WTM, WTN, WM, WN, BNMAJOR, BK, STAGGER, Epi>),
+            reinterpret_cast<const void*>(&dgemm_mfma_kernel<WTM, WTN, WM, WN, BNMAJOR, BK, STAGGER, INNER, Epi>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL((dgemm_mfma_kernel<WTM, WTN, WM, WN, BNMAJOR, BK, STAGGER, Epi>), dim3(p.gm * p.gn),
+    hipLaunchKernelGGL((dgemm_mfma_kernel<WTM, WTN, WM, WN, BNMAJOR, BK, STAGGER, INNER, Epi>), dim3(p.gm * p.gn),
                        dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, p, epi);
     MCML_HIP(hipGetLastError());
     return MCML_OK;
@@ -361,19 +384,22 @@ static inline int launch_gemm(hipStream_t s, int M, int N, int K, const double* 
     MCML_REQUIRE(BNMAJOR ? ldb >= N : ldb >= K, "dgemm: ldb %d too small", ldb);
     int id = force_tile >= 0 ? force_tile : pick_tile(M, N, K).id;
     switch (id) {
-    case 0: return launch_gemm_tile<5, 2, 2, 4, BNMAJOR, 16, false, Epi>(s, p, epi);
-    case 1: return launch_gemm_tile<4, 2, 2, 4, BNMAJOR, 16, false, Epi>(s, p, epi);
-    case 2: return launch_gemm_tile<4, 2, 2, 2, BNMAJOR, 16, false, Epi>(s, p, epi);
-    case 4: return launch_gemm_tile<5, 1, 2, 8, BNMAJOR, 16, false, Epi>(s, p, epi);
-    case 5: return launch_gemm_tile<4, 1, 2, 8, BNMAJOR, 16, false, Epi>(s, p, epi);
-    case 6: return launch_gemm_tile<5, 2, 2, 4, BNMAJOR, 32, false, Epi>(s, p, epi);
-    case 7: return launch_gemm_tile<5, 1, 2, 8, BNMAJOR, 32, false, Epi>(s, p, epi);
-    case 8: return launch_gemm_tile<5, 2, 2, 4, BNMAJOR, 16, true, Epi>(s, p, epi);
-    case 9: return launch_gemm_tile<5, 2, 2, 4, BNMAJOR, 32, true, Epi>(s, p, epi);
-    case 10: return launch_gemm_tile<4, 2, 2, 4, BNMAJOR, 16, true, Epi>(s, p, epi);
-    case 11: return launch_gemm_tile<5, 4, 2, 2, BNMAJOR, 16, false, Epi>(s, p, epi);
-    case 12: return launch_gemm_tile<5, 4, 2, 2, BNMAJOR, 32, false, Epi>(s, p, epi);
-    default: return launch_gemm_tile<2, 2, 2, 2, BNMAJOR, 16, false, Epi>(s, p, epi);
+    case 0: return launch_gemm_tile<5, 2, 2, 4, BNMAJOR, 16, false, 0, Epi>(s, p, epi);
+    case 1: return launch_gemm_tile<4, 2, 2, 4, BNMAJOR, 16, false, 0, Epi>(s, p, epi);
+    case 2: return launch_gemm_tile<4, 2, 2, 2, BNMAJOR, 16, false, 0, Epi>(s, p, epi);
+    case 4: return launch_gemm_tile<5, 1, 2, 8, BNMAJOR, 16, false, 0, Epi>(s, p, epi);
+    case 5: return launch_gemm_tile<4, 1, 2, 8, BNMAJOR, 16, false, 0, Epi>(s, p, epi);
+    case 6: return launch_gemm_tile<5, 2, 2, 4, BNMAJOR, 32, false, 0, Epi>(s, p, epi);
+    case 7: return launch_gemm_tile<5, 1, 2, 8, BNMAJOR, 32, false, 0, Epi>(s, p, epi);
+    case 8: return launch_gemm_tile<5, 2, 2, 4, BNMAJOR, 16, true, 0, Epi>(s, p, epi);
+    case 9: return launch_gemm_tile<5, 2, 2, 4, BNMAJOR, 32, true, 0, Epi>(s, p, epi);
+    case 10: return launch_gemm_tile<4, 2, 2, 4, BNMAJOR, 16, true, 0, Epi>(s, p, epi);
+    case 11: return launch_gemm_tile<5, 4, 2, 2, BNMAJOR, 16, false, 0, Epi>(s, p, epi);
+    case 12: return launch_gemm_tile<5, 4, 2, 2, BNMAJOR, 32, false, 0, Epi>(s, p, epi);
+    case 13: return launch_gemm_tile<5, 2, 2, 4, BNMAJOR, 32, false, 1, Epi>(s, p, epi);
+    case 14: return launch_gemm_tile<5, 2, 2, 4, BNMAJOR, 16, false, 2, Epi>(s, p, epi);
+    case 15: return launch_gemm_tile<5, 2, 2, 4, BNMAJOR, 16, false, 1, Epi>(s, p, epi);
+    default: return launch_gemm_tile<2, 2, 2, 2, BNMAJOR, 16, false, 0, Epi>(s, p, epi);
     }
 }
 

@@ -17,6 +17,7 @@
 #include "../../include/glmmr_mcml_c.h"
 #include "ctx.h"
 #include "dgemm_mfma.h"
+#include "dgemm_dlds.h"
 #include "glm.h"
 #include "reduce.h"
 #include "rng.h"
@@ -276,13 +277,25 @@ static int hmc_alloc(Ctx& c, int C)
     return MCML_OK;
 }
 
+// direct-to-LDS GEMM (dgemm_dlds.h) unless GLMMR_MCML_GEMM=reg asks for the register-staged one
+static bool use_dlds()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GLMMR_MCML_GEMM"); v = (e && !strcmp(e, "reg")) ? 0 : 1; }
+    return v == 1;
+}
+
 // MU = xb + ZL * X ; S = score
 static int hmc_forward(Ctx& c, const double* X, int ldx)
 {
     HmcState& h = c.hmc;
     EpiForward epi{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink};
     const int slot = c.prof.begin(c.stream, 0);
-    int rc = launch_gemm<false>(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
+    int rc;
+    if (use_dlds() && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
+        rc = launch_gemm_dlds(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
+    else
+        rc = launch_gemm<false>(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
     c.prof.end(c.stream, slot);
     return rc;
 }
@@ -293,7 +306,11 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
     ChainArrays ca = chain_arrays(h);
     EpiBackward epi{Xs, G, h.R.d(), h.UP.d(), h.V.ld, ca.e, ca.steps, s, glm_score_post(var_par, c.flink), mode};
     const int slot = c.prof.begin(c.stream, 1);
-    int rc = launch_gemm<false>(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
+    int rc;
+    if (use_dlds() && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
+        rc = launch_gemm_dlds(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
+    else
+        rc = launch_gemm<false>(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
     c.prof.end(c.stream, slot);
     return rc;
 }

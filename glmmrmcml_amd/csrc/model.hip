@@ -155,8 +155,13 @@ __global__ void k_transpose(const double* A, int lda, int rows, int cols, double
 int model_update_L(Ctx& c)
 {
     MCML_REQUIRE(c.n > 0 && c.have_L, "update_L: no model / L");
-    MCML_TRY(c.ZL.alloc(c.n, c.Q));
-    MCML_TRY(c.ZLT.alloc(c.Q, c.n));
+    // K-padding columns (zero) so that the direct-to-LDS GEMM needs no K guards
+    if (c.ZL.rows != c.n || c.ZL.cols != c.Q || !c.ZL.d()) {
+        MCML_TRY(c.ZL.alloc(c.n, c.Q, 16));
+        MCML_TRY(c.ZLT.alloc(c.Q, c.n, 16));
+        MCML_HIP(hipMemsetAsync(c.ZL.d(), 0, sizeof(double) * (size_t)c.ZL.ld * c.ZL.cols_alloc, c.stream));
+        MCML_HIP(hipMemsetAsync(c.ZLT.d(), 0, sizeof(double) * (size_t)c.ZLT.ld * c.ZLT.cols_alloc, c.stream));
+    }
     if (c.z_width > 0) {
         MCML_TRY(z_times(c, c.L.d(), c.L.ld, c.Q, c.ZL.d(), c.ZL.ld));
     } else {

@@ -1,0 +1,150 @@
+"""BASELINE-size checks through size-independent properties (the oracle would take hours at
+these sizes), plus structures and edge cases the small parity cases do not reach.
+
+Properties used:
+  * L L' reconstructs D and L^-1 (L x) = x at Q = 2000 / 5000 (factorisation + TRSM);
+  * mvn_ll is linear in the scale: D = t*R  =>  ll(t) = ll(1) - Q/2 log t - (1/t - 1) q/2, which
+    ties evaluations at different theta together without a reference value;
+  * the HMC sampler at cfg 2/3 sizes targets an exactly Gaussian posterior: the post-warm-up
+    draws of all chains have the closed-form mean, and accept probabilities are in (0, 1];
+  * sharded chains (two contexts with chain offsets) reproduce the unsharded chains exactly.
+"""
+import numpy as np
+import pytest
+
+from glmmrmcml_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("Q", [2000, 5000])
+def test_cholesky_and_trsm_at_baseline_sizes(Q):
+    from glmmrmcml_amd import api
+    d = synth.geospatial(Q)
+    rng = np.random.default_rng(1)
+    with api.Context(d["cov"], d["data"], d["eff_range"]) as ctx:
+        L = ctx.gen_D(d["theta"], chol=True)
+        D = ctx.gen_D(d["theta"], chol=False)
+        assert np.allclose(np.triu(L, 1), 0)
+        x = rng.normal(size=Q)
+        assert np.abs(L @ (L.T @ x) - D @ x).max() < 1e-11 * np.abs(D @ x).max()
+        # u = L z  =>  quadratic form = |z|^2 ; logdet from diag(L)
+        m = 7
+        z = rng.normal(size=(Q, m))
+        ctx.set_u(np.asfortranarray(L @ z))
+        ll = ctx.mvn_ll(d["theta"])
+        want = np.mean(-0.5 * Q * np.log(2 * np.pi) - np.log(np.diag(L)).sum() - 0.5 * (z ** 2).sum(0))
+        assert abs(ll - want) < 1e-9 * abs(want)
+        # scale linearity: theta0 -> t * theta0
+        t = 1.7
+        ll_t = ctx.mvn_ll([d["theta"][0] * t, d["theta"][1]])
+        q = (z ** 2).sum(0).mean()
+        assert abs(ll_t - (want - 0.5 * Q * np.log(t) - 0.5 * (1 / t - 1) * q)) < 1e-9 * abs(want)
+
+
+@pytest.mark.parametrize("n,chains", [(2000, 256), (5000, 1024)])
+def test_sampler_at_config_sizes_hits_the_gaussian_posterior(n, chains):
+    from glmmrmcml_amd import api
+    d = synth.geospatial(n)
+    with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"]) as ctx:
+        ctx.update_L(d["theta"])
+        diag, flags, probs = ctx.hmc_sample(d["beta"], d["sigma"], 60, chains, 5.0, 10, 0.9, seed=3,
+                                            chains=chains, want_trace=True)
+        u = ctx.get_u()
+        L = ctx.gen_D(d["theta"], chol=True)
+    assert u.shape == (n, chains)
+    assert np.all(probs > 0) and np.all(probs <= 1) and 0.5 < diag["accept_rate"] <= 1
+    # posterior mean of u = L v:  L S L'(y - xb)/s^2 with S = (I + L'L/s^2)^-1  (Z = I)
+    s2 = d["sigma"] ** 2
+    S = np.linalg.inv(np.eye(n) + L.T @ L / s2)
+    mu_u = L @ (S @ (L.T @ (d["y"] - d["X"] @ d["beta"]))) / s2
+    err = u.mean(1) - mu_u
+    sd_u = np.sqrt(np.einsum("ij,jk,ik->i", L, S, L) / chains)
+    # 60 warm-up proposals of 10 steps have not fully mixed: allow 6 sd + 10% of the signal
+    assert np.mean(np.abs(err) < 6 * sd_u + 0.1 * np.abs(mu_u).max()) > 0.99
+
+
+def test_sharded_chains_equal_unsharded_chains():
+    from glmmrmcml_amd import api
+    d = synth.geospatial(300, seed=4)
+    args = (d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"])
+    with api.Context(*args) as ctx:
+        ctx.update_L(d["theta"])
+        ctx.hmc_sample(d["beta"], d["sigma"], 12, 16, 1.0, 6, 0.9, seed=8, chains=16)
+        whole = ctx.get_u()
+    parts = []
+    for r in range(2):
+        with api.Context(*args, rank=r, world=1) as ctx:
+            ctx.update_L(d["theta"])
+            ctx.hmc_sample(d["beta"], d["sigma"], 12, 8, 1.0, 6, 0.9, seed=8, chains=8, chain_offset=8 * r)
+            parts.append(ctx.get_u())
+    assert np.array_equal(np.concatenate(parts, axis=1), whole)
+
+
+def test_mixed_block_structure(orc):
+    """one cov matrix holding diagonal gr blocks, small ar1 blocks and a large dense fexp block at an
+    odd offset: every mvn_ll code path in one call"""
+    from glmmrmcml_amd import api
+    rng = np.random.default_rng(5)
+    rows, data = [], []
+    for b in range(3):                         # 3 diagonal blocks of dim 1
+        rows.append([b, 1, 1, 1, 0]); data.append([b + 1.0])
+    nt = 5
+    for b in range(4):                         # 4 gr*ar1 blocks of dim 5
+        rows.append([3 + b, nt, 1, 1, 1]); rows.append([3 + b, nt, 3, 1, 2])
+        data.append(np.r_[np.full(nt, b + 1.0), np.arange(1.0, nt + 1)])
+    nd = 301                                   # dense fexp block, starts at the odd offset 23
+    xy = rng.random((nd, 2))
+    rows.append([7, nd, 7, 2, 3]); data.append(np.r_[xy[:, 0], xy[:, 1]])
+    rows.append([8, 1, 1, 1, 0]); data.append([9.0])          # a trailing diagonal block
+    cov = np.array(rows, dtype=np.int32)
+    data = np.concatenate([np.atleast_1d(np.asarray(x, float)) for x in data])
+    theta = np.array([0.3, 0.4, 0.6, 0.25, 0.1])
+    Q = 3 + 4 * nt + nd + 1
+    u = rng.normal(size=(Q, 11)) * 0.4
+    got = api.mvn_ll(cov, data, np.zeros(len(rows)), theta, u)
+    want = orc.mvn_ll(cov, data, np.zeros(len(rows)), theta, u)
+    assert abs(got - want) < 1e-10 * abs(want)
+    with api.Context(cov, data, np.zeros(len(rows))) as ctx:
+        L = ctx.gen_D(theta, chol=True)
+    Lo = orc.gen_D(cov, data, np.zeros(len(rows)), theta, chol=True)
+    assert np.abs(L - Lo).max() < 1e-10
+
+
+def test_edge_shapes(orc):
+    from glmmrmcml_amd import api, _lib
+    # Q = 1, one column
+    cov = np.array([[0, 1, 1, 1, 0]], dtype=np.int32)
+    assert abs(api.mvn_ll(cov, [1.0], [0.0], [0.5], [[0.3]]) - orc.mvn_ll(cov, [1.0], [0.0], [0.5], [[0.3]])) < 1e-14
+    # n = 1 observation, P = 1
+    d = synth.cluster_rct(ncl=2, nt=1, nind=1, seed=1)
+    with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"][:, :2], d["y"], "binomial", "logit") as ctx:
+        ctx.update_L(d["theta"])
+        ctx.hmc_sample(d["beta"][:2], 1.0, 3, 2, 0.5, 3, 0.9, seed=1)
+        assert ctx.get_u().shape == (d["Q"], 3)
+    # zero columns of u is an error, not a crash
+    with api.Context(cov, [1.0], [0.0]) as ctx:
+        with pytest.raises(_lib.McmlError):
+            ctx.mvn_ll([0.5])
+    # dimensions that do not match
+    with pytest.raises(_lib.McmlError):
+        api.Context(d["cov"], d["data"], d["eff_range"], d["Z"][:, :-1], d["X"], d["y"], "binomial", "logit")
+
+
+def test_longitudinal_poisson_reduced(orc):
+    """config 5's structure (all-diagonal D, indicator Z, poisson-log) at reduced scale"""
+    from glmmrmcml_amd import api
+    from oracle import drivers
+    d = synth.longitudinal(nsubj=60, nvisit=4, seed=6)
+    args = (d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"])
+    rng = np.random.default_rng(2)
+    L = orc.gen_D(d["cov"], d["data"], d["eff_range"], d["theta"], chol=True)
+    u = np.asfortranarray(L @ rng.normal(size=(d["Q"], 33)))
+    mod = drivers.Model(*args, d["family"], d["link"])
+    got = api.mcml_optim(*args, u, d["family"], d["link"], d["start"], mcnr=True)
+    want = drivers.mcml_optim(mod, u, d["start"], mcnr=True)
+    assert np.abs(got["beta"] - want["beta"]).max() < 1e-8
+    assert np.abs(got["theta"] - want["theta"]).max() < 2e-6
+    H = api.mcml_hess(*args, u, d["family"], d["link"], np.r_[want["beta"], want["theta"], 1.0], tol=1e-4)
+    Ho = drivers.mcml_hess(mod, u, np.r_[want["beta"], want["theta"], 1.0], tol=1e-4)
+    assert np.abs(H - Ho).max() < 1e-4 * np.abs(Ho).max()

@@ -338,10 +338,24 @@ def mcml_simlik(cov, data, eff_range, Z, X, y, u, family, link, start, trace=0, 
 
 def mcml_optim_sparse(cov, data, eff_range, Ap, Ai, Z, X, y, u, family, link, start, trace=0, mcnr=False,
                       maxfun=0):
-    """mcml_optim_sparse(...)   (src/mcml_optim.cpp:147-184)"""
-    b, t, s = _fit_call(_lib.lib().glmmr_mcml_optim_sparse, (cov, data, eff_range, Z, X, y, family, link), u,
-                        start, [int(trace), int(mcnr)], sparse=(Ap, Ai), maxfun=maxfun)
-    return dict(beta=b, theta=t[:_npar_of(cov)], sigma=s)
+    """mcml_optim_sparse(...) -> dict(beta, theta, sigma, Ap, Ai, Ax, D)   (src/mcml_optim.cpp:147-184):
+    Ap/Ai/Ax = the unit lower LDL' factor of D(theta) without its diagonal, D its pivots."""
+    p, keep = _problem(cov, data, eff_range, Z, X, y, family, link)
+    u = _f(u); start = _f(start).ravel()
+    cv = keep["cov"]
+    lib = _lib.lib()
+    cap = lib.glmmr_mcml_sparse_factor_nnz(cv.ctypes.data_as(c_ip), cv.shape[0], _p(keep["data"]), keep["data"].size)
+    R = _npar_of(cov)
+    b = np.zeros(p.P); t = np.zeros(R); sg = C.c_double()
+    Lp = np.zeros(p.Q + 1, dtype=np.int32); Li = np.zeros(max(cap, 1), dtype=np.int32)
+    Lx = np.zeros(max(cap, 1)); D = np.zeros(p.Q)
+    Ap_, Ai_ = _i(Ap).ravel(), _i(Ai).ravel()
+    e = Ext(0, 1, int(maxfun), 0)
+    _lib.check(lib.glmmr_mcml_optim_sparse(C.byref(p), Ap_.ctypes.data_as(c_ip), Ai_.ctypes.data_as(c_ip), Ai_.size,
+                                           _p(u), u.shape[1], _p(start), start.size, int(trace), int(mcnr),
+                                           C.byref(e), _p(b), _p(t), C.byref(sg), Lp.ctypes.data_as(c_ip),
+                                           Li.ctypes.data_as(c_ip), _p(Lx), _p(D), cap))
+    return dict(beta=b, theta=t, sigma=sg.value, Ap=Lp, Ai=Li[:cap], Ax=Lx[:cap], D=D)
 
 
 def mcml_simlik_sparse(cov, data, eff_range, Ap, Ai, Z, X, y, u, family, link, start, trace=0, maxfun=0):

@@ -410,16 +410,62 @@ extern "C" int glmmr_mcml_simlik(const glmmr_mcml_problem* prob, const double* u
     return glmmr_mcml_ctx_simlik(g.h, start, nstart, trace, ext, beta, theta, sigma);
 }
 
+// LDL' factor of the block-diagonal D(theta) in the layout SparseChol hands back
+// (mcml_optim.cpp:180-182: chol_->L->{Ap,Ai,Ax}, chol_->D): L unit lower triangular stored
+// column-compressed WITHOUT its diagonal, D the pivots; chol(D) = L * diag(sqrt(D)).
+// From the dense block factors: L_ldl = L_chol * diag(1 / diag(L_chol)), D = diag(L_chol)^2.
+static int sparse_factor_nnz(const Ctx& c)
+{
+    long nnz = 0;
+    for (const auto& b : c.cov.blocks) if (!b.all_gr) nnz += (long)b.dim * (b.dim - 1) / 2;
+    return (int)nnz;
+}
+
+extern "C" int glmmr_mcml_sparse_factor_nnz(const int32_t* cov, int cov_rows, const double* data, int data_len)
+{
+    CovSpec cs;
+    if (cs.parse(cov, cov_rows, data, data_len, nullptr, 0)) return -1;
+    long nnz = 0;
+    for (const auto& b : cs.blocks) if (!b.all_gr) nnz += (long)b.dim * (b.dim - 1) / 2;
+    return (int)nnz;
+}
+
+static int sparse_factor(Ctx& c, const double* theta, int32_t* Lp, int32_t* Li, double* Lx, double* D)
+{
+    MCML_TRY(mvn_gen_L(c, theta, true));
+    std::vector<double> blk;
+    int nz = 0;
+    for (const auto& b : c.cov.blocks) {
+        blk.assign((size_t)b.dim * b.dim, 0.0);
+        MCML_TRY(download_matrix(blk.data(), b.dim, c.L.at(b.matstart, b.matstart), c.L.ld, b.dim, b.dim, c.stream));
+        for (int j = 0; j < b.dim; ++j) {
+            const double d = blk[j + (size_t)j * b.dim];
+            Lp[b.matstart + j] = nz;
+            D[b.matstart + j] = d * d;
+            if (!b.all_gr)
+                for (int i = j + 1; i < b.dim; ++i) { Li[nz] = b.matstart + i; Lx[nz] = blk[i + (size_t)j * b.dim] / d; ++nz; }
+        }
+    }
+    Lp[c.Q] = nz;
+    return MCML_OK;
+}
+
 extern "C" int glmmr_mcml_optim_sparse(const glmmr_mcml_problem* prob, const int32_t* Ap, const int32_t* Ai,
                                        int nnz, const double* u, int ucols, const double* start, int nstart,
                                        int trace, int mcnr, const glmmr_mcml_ext* ext, double* beta, double* theta,
-                                       double* sigma)
+                                       double* sigma, int32_t* Lp, int32_t* Li, double* Lx, double* D, int lcap)
 {
     CtxGuard g;
     MCML_TRY(open_ctx(prob, ext, g));
     MCML_TRY(check_pattern(g.h->c, Ap, Ai, nnz));
     MCML_TRY(glmmr_mcml_set_u(g.h, u, prob->Q, ucols, ucols));
-    return glmmr_mcml_ctx_optim(g.h, start, nstart, trace, mcnr, ext, beta, theta, sigma);
+    MCML_TRY(glmmr_mcml_ctx_optim(g.h, start, nstart, trace, mcnr, ext, beta, theta, sigma));
+    if (Lp && Li && Lx && D) {
+        MCML_REQUIRE(lcap >= sparse_factor_nnz(g.h->c), "optim_sparse: factor needs %d entries, %d given",
+                     sparse_factor_nnz(g.h->c), lcap);
+        MCML_TRY(sparse_factor(g.h->c, theta, Lp, Li, Lx, D));
+    }
+    return MCML_OK;
 }
 
 extern "C" int glmmr_mcml_simlik_sparse(const glmmr_mcml_problem* prob, const int32_t* Ap, const int32_t* Ai,

@@ -192,7 +192,13 @@ int glmmr_mcml_simlik(const glmmr_mcml_problem* prob, const double* u, int ucols
 int glmmr_mcml_optim_sparse(const glmmr_mcml_problem* prob, const int32_t* Ap, const int32_t* Ai, int nnz,
                             const double* u, int ucols, const double* start, int nstart, int trace,
                             int mcnr, const glmmr_mcml_ext* ext, double* beta, double* theta,
-                            double* sigma);
+                            double* sigma,
+                            /* LDL' factor of D(theta), as the reference returns it (mcml_optim.cpp:180-182):
+                             * unit lower L column-compressed without its diagonal (Lp: Q+1, Li/Lx: lcap
+                             * entries, size from glmmr_mcml_sparse_factor_nnz) and the pivots D (Q).
+                             * All four nullable. */
+                            int32_t* Lp, int32_t* Li, double* Lx, double* D, int lcap);
+int glmmr_mcml_sparse_factor_nnz(const int32_t* cov, int cov_rows, const double* data, int data_len);
 int glmmr_mcml_simlik_sparse(const glmmr_mcml_problem* prob, const int32_t* Ap, const int32_t* Ai, int nnz,
                              const double* u, int ucols, const double* start, int nstart, int trace,
                              const glmmr_mcml_ext* ext, double* beta, double* theta, double* sigma);

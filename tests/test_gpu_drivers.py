@@ -93,6 +93,13 @@ def test_sparse_exports_use_the_block_path(orc):
     sp = api.mcml_optim_sparse(d["cov"], d["data"], d["eff_range"], D.indptr, D.indices, d["Z"], d["X"], d["y"], u,
                                d["family"], d["link"], d["start"], mcnr=True)
     assert np.array_equal(dense["beta"], sp["beta"]) and np.array_equal(dense["theta"], sp["theta"])
+    # the returned LDL' factor rebuilds chol(D(theta)) the way the R side does (R6ModelExtMCML.R:313-315):
+    # L = sparse_L(Ap, Ai, Ax) %*% Diagonal(sqrt(D))
+    Q = d["Q"]
+    Lu = sparse.csc_matrix((sp["Ax"], sp["Ai"], sp["Ap"]), shape=(Q, Q)).toarray() + np.eye(Q)
+    Lc = Lu @ np.diag(np.sqrt(sp["D"]))
+    Lo = orc.gen_D(d["cov"], d["data"], d["eff_range"], sp["theta"], chol=True)
+    assert np.abs(Lc - Lo).max() < 1e-12
     bad = D.indices.copy(); bad[-1] = 0          # an entry outside the blocks
     with pytest.raises(_lib.McmlError):
         api.mcml_optim_sparse(d["cov"], d["data"], d["eff_range"], D.indptr, bad, d["Z"], d["X"], d["y"], u,

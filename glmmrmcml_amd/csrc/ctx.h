@@ -24,6 +24,18 @@ struct HmcState {
     int partial_slots = 0;
 };
 
+// ZL = Z L held as padded-CSR (ELL) rows plus its transpose in CSR: used by the sampler
+// instead of the dense n x Q products when Z is indicator-like and every covariance block is
+// diagonal or small, so that a row of ZL has only a few nonzeros (configs 1, 4, 5): the two
+// products are then gathers bound by HBM bandwidth, not n x Q x C GEMMs.
+struct SparseZL {
+    bool possible = false, active = false, built = false;
+    int W = 0;                       // ELL width
+    long nnz = 0;
+    DevBuf ell_col, ell_src, ell_z, ell_val;   // n x W (column-major): column of ZL, flat index into L, Z value, value
+    DevBuf csr_ptr, csr_i, csr_pos;            // rows of ZL' : q -> (observation, position in ell_val)
+};
+
 // HIP-event timing of the dominant kernels, on the stream they are launched on
 // (bench.py's roofline line).  kind 0 = HMC forward GEMM, 1 = HMC backward GEMM.
 struct KernelProf {
@@ -63,6 +75,8 @@ struct Ctx {
     int n = 0, Q = 0, P = 0, flink = 0, link_code = 0;
     int z_width = 0;            // > 0: Z also held as padded-CSR rows of this width
     DevBuf z_idx, z_val;        // n x z_width (column-major)
+    std::vector<int> h_zidx; std::vector<double> h_zval;   // host copy of the same
+    SparseZL sp;
     CovSpec cov;
     DevMat Z, X;                // n x Q, n x P
     DevBuf y;                   // n
@@ -118,7 +132,7 @@ int model_setup(Ctx& c, const double* Z, const double* X, const double* y);
 int allreduce_host(Ctx& c, double* vals, int n);
 int model_update_beta(Ctx& c, const double* beta);          // xb = X beta
 int model_update_zu(Ctx& c);                                // ZU = Z U (cached)
-int model_update_L(Ctx& c);                                 // ZL = Z L, ZLT
+int model_update_L(Ctx& c);                                 // ZL = Z L, ZLT (dense) or the ELL/CSR pair (sparse)
 int model_loglik_sum(Ctx& c, double var_par, double* sum_out);
 int model_mcnr_stats(Ctx& c, double var_par, double* stats /* P*P + P + 2 */);
 int mcnr_finish(int P, const double* stats, const double* beta, double* beta_out, double* sigma_out);

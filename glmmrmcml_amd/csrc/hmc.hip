@@ -48,6 +48,11 @@ static ChainArrays chain_arrays(const HmcState& h)
 // forward: MU = xb + acc ; S = score(y, MU)          (mcmlmodel.h:160-162,169-276)
 struct EpiForward {
     double* MU; double* S; int ld; const double* xb; const double* y; int flink;
+    __device__ __forceinline__ void elem(int m, int n, double accv) const {
+        const double mu = xb[m] + accv;
+        MU[m + (size_t)n * ld] = mu;
+        S[m + (size_t)n * ld] = glm_score(y[m], mu, flink);
+    }
     template <int TM, int TN>
     __device__ __forceinline__ void operator()(d4 (&acc)[TM][TN], int mB, int nB, int lane, int M, int N,
                                                int) const {
@@ -77,6 +82,24 @@ struct EpiForward {
 struct EpiBackward {
     const double* Xs; double* G; double* R; double* UP; int ld;
     const double* e; const int* steps; int s; double post; int mode;
+    __device__ __forceinline__ void elem(int m, int n, double accv) const {
+        int st = 0; double en = 0.0;
+        if (mode == 1) { st = steps[n]; en = e[n]; if (s >= st) return; }
+        const size_t off = m + (size_t)n * ld;
+        const double x = Xs[off];
+        double g = -1.0 * x;
+        g = g + post * accv;
+        G[off] = g;
+        if (mode == 1) {
+            double rr = R[off];
+            rr = rr + (en / 2) * g;
+            if (s + 1 < st) {
+                rr = rr + (en / 2) * g;
+                UP[off] = x + en * rr;
+            }
+            R[off] = rr;
+        }
+    }
     template <int TM, int TN>
     __device__ __forceinline__ void operator()(d4 (&acc)[TM][TN], int mB, int nB, int lane, int M, int N,
                                                int) const {
@@ -110,6 +133,55 @@ struct EpiBackward {
             }
     }
 };
+
+// ------------------------------------------------------------------ sparse ZL products
+// forward: acc = sum_k ZL[i, col_k] X[col_k, c]   (ELL row of observation i)
+template <class Epi>
+__global__ __launch_bounds__(256) void k_sp_forward(int n, int C, int W, const int* col, const double* val,
+                                                    const double* X, int ldx, Epi epi)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int c = blockIdx.y; c < C; c += gridDim.y) {
+        const double* x = X + (size_t)c * ldx;
+        double acc = 0.0;
+        for (int k = 0; k < W; ++k) acc += val[i + (size_t)k * n] * x[col[i + (size_t)k * n]];
+        epi.elem(i, c, acc);
+    }
+}
+
+// backward: acc = sum_t ZL[i_t, q] S[i_t, c]   (CSR row q of ZL')
+template <class Epi>
+__global__ __launch_bounds__(256) void k_sp_backward(int Q, int C, const int* ptr, const int* ci, const int* cp,
+                                                     const double* val, const double* S, int lds, Epi epi)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Q) return;
+    const int t0 = ptr[q], t1 = ptr[q + 1];
+    for (int c = blockIdx.y; c < C; c += gridDim.y) {
+        const double* sc = S + (size_t)c * lds;
+        double acc = 0.0;
+        for (int t = t0; t < t1; ++t) acc += val[cp[t]] * sc[ci[t]];
+        epi.elem(q, c, acc);
+    }
+}
+
+// backward for long rows (tens to hundreds of observations per random effect): one wave per
+// (q, chain), lanes stride the row, fixed-order wave reduction
+template <class Epi>
+__global__ __launch_bounds__(256) void k_sp_backward_wave(int Q, int C, const int* ptr, const int* ci, const int* cp,
+                                                          const double* val, const double* S, int lds, Epi epi)
+{
+    const int q = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int t0 = ptr[q], t1 = ptr[q + 1];
+    for (int c = blockIdx.y * 4 + w; c < C; c += gridDim.y * 4) {
+        const double* sc = S + (size_t)c * lds;
+        double acc = 0.0;
+        for (int t = t0 + lane; t < t1; t += 64) acc += val[cp[t]] * sc[ci[t]];
+        acc = wave_sum(acc);
+        if (lane == 0) epi.elem(q, c, acc);
+    }
+}
 
 // ------------------------------------------------------------------ per-chain kernels
 __global__ __launch_bounds__(256) void k_hmc_init(double* V, int ld, int Q, ChainArrays ca, uint64_t seed,
@@ -292,7 +364,12 @@ static int hmc_forward(Ctx& c, const double* X, int ldx)
     EpiForward epi{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink};
     const int slot = c.prof.begin(c.stream, 0);
     int rc;
-    if (use_dlds() && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
+    if (c.sp.active) {
+        const int gy = h.C < 256 ? h.C : 256;
+        hipLaunchKernelGGL((k_sp_forward<EpiForward>), dim3((c.n + 255) / 256, gy), dim3(256), 0, c.stream, c.n, h.C,
+                           c.sp.W, c.sp.ell_col.as<int>(), c.sp.ell_val.d(), X, ldx, epi);
+        rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
+    } else if (use_dlds() && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
         rc = launch_gemm_dlds(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
     else
         rc = launch_gemm<false>(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
@@ -307,7 +384,19 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
     EpiBackward epi{Xs, G, h.R.d(), h.UP.d(), h.V.ld, ca.e, ca.steps, s, glm_score_post(var_par, c.flink), mode};
     const int slot = c.prof.begin(c.stream, 1);
     int rc;
-    if (use_dlds() && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
+    if (c.sp.active && c.sp.nnz >= 24L * c.Q) {
+        int gy = (h.C + 3) / 4; if (gy > 64) gy = 64;
+        hipLaunchKernelGGL((k_sp_backward_wave<EpiBackward>), dim3(c.Q, gy), dim3(256), 0, c.stream, c.Q, h.C,
+                           c.sp.csr_ptr.as<int>(), c.sp.csr_i.as<int>(), c.sp.csr_pos.as<int>(), c.sp.ell_val.d(),
+                           h.S.d(), h.S.ld, epi);
+        rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
+    } else if (c.sp.active) {
+        const int gy = h.C < 256 ? h.C : 256;
+        hipLaunchKernelGGL((k_sp_backward<EpiBackward>), dim3((c.Q + 255) / 256, gy), dim3(256), 0, c.stream, c.Q, h.C,
+                           c.sp.csr_ptr.as<int>(), c.sp.csr_i.as<int>(), c.sp.csr_pos.as<int>(), c.sp.ell_val.d(),
+                           h.S.d(), h.S.ld, epi);
+        rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
+    } else if (use_dlds() && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
         rc = launch_gemm_dlds(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
     else
         rc = launch_gemm<false>(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
@@ -331,7 +420,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
                uint32_t iter_idx, const double* inj_init, const double* inj_mom, uint8_t* flags_out,
                double* probs_out, glmmr_mcml_hmc_diag* diag, int* ncols_out)
 {
-    MCML_REQUIRE(c.n > 0 && c.have_L && c.ZL.d(), "hmc: model / L not set (call update_L or set_L first)");
+    MCML_REQUIRE(c.n > 0 && c.have_L && (c.ZL.d() || c.sp.active), "hmc: model / L not set (call update_L or set_L first)");
     MCML_REQUIRE(o && o->warmup >= 0 && o->nsamp > 0 && o->max_steps >= 1 && o->lambda > 0,
                  "hmc: bad options");
     MCML_REQUIRE(beta, "hmc: beta is null");
@@ -430,7 +519,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
 int hmc_dbg_log_prob_grad(Ctx& c, const double* beta, double var_par, const double* V, int ncols, double* lp,
                           double* G)
 {
-    MCML_REQUIRE(c.n > 0 && c.have_L && c.ZL.d(), "log_prob_grad: model / L not set");
+    MCML_REQUIRE(c.n > 0 && c.have_L && (c.ZL.d() || c.sp.active), "log_prob_grad: model / L not set");
     MCML_TRY(model_update_beta(c, beta));
     MCML_TRY(hmc_alloc(c, ncols));
     HmcState& h = c.hmc;

@@ -63,6 +63,7 @@ int model_setup(Ctx& c, const double* Z, const double* X, const double* y)
                 double v = Z[i + (size_t)j * n];
                 if (v != 0.0) { int k = cnt[i]++; zi[i + (size_t)k * n] = j; zv[i + (size_t)k * n] = v; }
             }
+        c.h_zidx = zi; c.h_zval = zv;
         MCML_TRY(c.z_idx.ensure(sizeof(int) * zi.size()));
         MCML_TRY(c.z_val.ensure(sizeof(double) * zv.size()));
         MCML_HIP(hipMemcpyAsync(c.z_idx.p, zi.data(), sizeof(int) * zi.size(), hipMemcpyHostToDevice, c.stream));
@@ -150,11 +151,81 @@ __global__ void k_transpose(const double* A, int lda, int rows, int cols, double
     }
 }
 
-// ZL_ = Z * L (mcmlmodel.h:104-106) and its transpose (so that both HMC products
-// read their A operand M-contiguous)
+// ---- sparse ZL (configs whose D has only diagonal / small blocks and whose Z is indicator-like)
+__global__ void k_ell_fill(const int* src, const double* z, const double* L, long total, double* val)
+{
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < total) val[e] = z[e] * L[src[e]];
+}
+
+static int sparse_zl_setup(Ctx& c)
+{
+    SparseZL& sp = c.sp;
+    sp.built = true; sp.possible = false;
+    if (const char* e = getenv("GLMMR_MCML_ZL")) if (!strcmp(e, "dense")) return MCML_OK;
+    if (c.z_width <= 0 || c.cov.B <= 0 || c.maxdim_large > 0) return MCML_OK;
+    if ((double)c.Q * pad_ld(c.Q) >= 2.0e9) return MCML_OK;           // flat index into L must fit an int
+    const int n = c.n, Q = c.Q, zw = c.z_width, ldL = pad_ld(Q);
+    std::vector<int> blk_of(Q), start_of(Q);
+    for (int b = 0; b < c.cov.B; ++b)
+        for (int k = 0; k < c.cov.blocks[b].dim; ++k) { blk_of[c.cov.blocks[b].matstart + k] = b; start_of[c.cov.blocks[b].matstart + k] = c.cov.blocks[b].matstart; }
+    // row i of ZL = sum over the nonzeros (j, z) of row i of Z of z * L[j, start(j) .. j]
+    int W = 0; long nnz = 0;
+    std::vector<int> width(n, 0);
+    for (int i = 0; i < n; ++i) {
+        int w = 0;
+        for (int k = 0; k < zw; ++k) { if (c.h_zval[i + (size_t)k * n] == 0.0) continue; int j = c.h_zidx[i + (size_t)k * n]; w += j - start_of[j] + 1; }
+        width[i] = w; nnz += w; if (w > W) W = w;
+    }
+    if (W <= 0 || W > 64) return MCML_OK;
+    std::vector<int> col((size_t)n * W, 0), src((size_t)n * W, 0);
+    std::vector<double> zz((size_t)n * W, 0.0);
+    std::vector<int> cnt(Q, 0);
+    for (int i = 0; i < n; ++i) {
+        int w = 0;
+        for (int k = 0; k < zw; ++k) {
+            double z = c.h_zval[i + (size_t)k * n];
+            if (z == 0.0) continue;
+            int j = c.h_zidx[i + (size_t)k * n];
+            for (int t = start_of[j]; t <= j; ++t) { col[i + (size_t)w * n] = t; src[i + (size_t)w * n] = j + t * ldL; zz[i + (size_t)w * n] = z; ++cnt[t]; ++w; }
+        }
+    }
+    std::vector<int> ptr(Q + 1, 0);
+    for (int q = 0; q < Q; ++q) ptr[q + 1] = ptr[q] + cnt[q];
+    std::vector<int> ci((size_t)nnz), cp((size_t)nnz), fill(ptr.begin(), ptr.end() - 1);
+    for (int i = 0; i < n; ++i)
+        for (int w = 0; w < width[i]; ++w) { int q = col[i + (size_t)w * n]; int t = fill[q]++; ci[t] = i; cp[t] = i + w * n; }
+    const size_t tot = (size_t)n * W;
+    MCML_TRY(sp.ell_col.ensure(sizeof(int) * tot)); MCML_TRY(sp.ell_src.ensure(sizeof(int) * tot));
+    MCML_TRY(sp.ell_z.ensure(sizeof(double) * tot)); MCML_TRY(sp.ell_val.ensure(sizeof(double) * tot));
+    MCML_TRY(sp.csr_ptr.ensure(sizeof(int) * (size_t)(Q + 1))); MCML_TRY(sp.csr_i.ensure(sizeof(int) * (size_t)(nnz + 1)));
+    MCML_TRY(sp.csr_pos.ensure(sizeof(int) * (size_t)(nnz + 1)));
+    MCML_HIP(hipMemcpyAsync(sp.ell_col.p, col.data(), sizeof(int) * tot, hipMemcpyHostToDevice, c.stream));
+    MCML_HIP(hipMemcpyAsync(sp.ell_src.p, src.data(), sizeof(int) * tot, hipMemcpyHostToDevice, c.stream));
+    MCML_HIP(hipMemcpyAsync(sp.ell_z.p, zz.data(), sizeof(double) * tot, hipMemcpyHostToDevice, c.stream));
+    MCML_HIP(hipMemcpyAsync(sp.csr_ptr.p, ptr.data(), sizeof(int) * (size_t)(Q + 1), hipMemcpyHostToDevice, c.stream));
+    MCML_HIP(hipMemcpyAsync(sp.csr_i.p, ci.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c.stream));
+    MCML_HIP(hipMemcpyAsync(sp.csr_pos.p, cp.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c.stream));
+    MCML_HIP(hipStreamSynchronize(c.stream));
+    sp.W = W; sp.nnz = nnz; sp.possible = true;
+    return MCML_OK;
+}
+
+// ZL_ = Z * L (mcmlmodel.h:104-106): dense with its transpose (so that both HMC products read
+// their A operand M-contiguous), or the ELL/CSR pair when ZL is sparse
 int model_update_L(Ctx& c)
 {
     MCML_REQUIRE(c.n > 0 && c.have_L, "update_L: no model / L");
+    if (!c.sp.built) MCML_TRY(sparse_zl_setup(c));
+    if (c.sp.possible && c.L.ld == pad_ld(c.Q)) {
+        const long tot = (long)c.n * c.sp.W;
+        hipLaunchKernelGGL(k_ell_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c.stream,
+                           c.sp.ell_src.as<int>(), c.sp.ell_z.d(), c.L.d(), tot, c.sp.ell_val.d());
+        MCML_HIP(hipGetLastError());
+        c.sp.active = true;
+        return MCML_OK;
+    }
+    c.sp.active = false;
     // K-padding columns (zero) so that the direct-to-LDS GEMM needs no K guards
     if (c.ZL.rows != c.n || c.ZL.cols != c.Q || !c.ZL.d()) {
         MCML_TRY(c.ZL.alloc(c.n, c.Q, 16));
@@ -165,7 +236,6 @@ int model_update_L(Ctx& c)
     if (c.z_width > 0) {
         MCML_TRY(z_times(c, c.L.d(), c.L.ld, c.Q, c.ZL.d(), c.ZL.ld));
     } else {
-        // L is lower triangular: N-major view of L^T is not needed; plain K-major product
         EpiAxpby epi{c.ZL.d(), c.ZL.ld, 1.0, 0.0};
         MCML_TRY(launch_gemm<false>(c.stream, c.n, c.Q, c.Q, c.Z.d(), c.Z.ld, c.L.d(), c.L.ld, epi));
     }

@@ -124,3 +124,25 @@ def test_many_chains_recover_gaussian_posterior(orc):
     assert np.abs(np.cov(v) - S).max() < 0.12 * np.abs(S).max()
     assert 0.6 < diag["accept_rate"] <= 1.0
     ctx.close()
+
+
+def test_sparse_and_dense_zl_operators_agree(monkeypatch):
+    """configs 1/4/5: the ELL/CSR ZL operator and the dense MFMA GEMMs are the same sampler"""
+    from glmmrmcml_amd import api
+    for gen, kw in ((synth.stepped_wedge, dict(ncl=9, nt=6, nind=12)), (synth.longitudinal, dict(nsubj=50, nvisit=4))):
+        d = gen(**kw)
+        out = {}
+        for mode in ("sparse", "dense"):
+            if mode == "dense":
+                monkeypatch.setenv("GLMMR_MCML_ZL", "dense")
+            else:
+                monkeypatch.delenv("GLMMR_MCML_ZL", raising=False)
+            with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"]) as ctx:
+                ctx.update_L(d["theta"])
+                diag, flags, probs = ctx.hmc_sample(d["beta"], 1.0, 15, 24, 0.4, 8, 0.9, seed=77, chains=12,
+                                                    want_trace=True)
+                out[mode] = (ctx.get_u(), flags.copy(), probs.copy())
+        monkeypatch.delenv("GLMMR_MCML_ZL", raising=False)
+        assert np.array_equal(out["sparse"][1], out["dense"][1])
+        assert np.abs(out["sparse"][2] - out["dense"][2]).max() < 1e-9
+        assert np.abs(out["sparse"][0] - out["dense"][0]).max() < 1e-8

@@ -150,14 +150,18 @@ def main():
 
     if rank == 0:
         launches = prof["fwd_n"] + prof["bwd_n"]
-        avg_s = (prof["fwd_ms"] + prof["bwd_ms"]) / max(1, launches) * 1e-3
-        flops = 2.0 * n * n * C                      # algorithmic flops of one n x Q x C product
-        achieved = flops / avg_s / 1e12 if launches else 0.0
+        gemm_s = (prof["fwd_ms"] + prof["bwd_ms"]) * 1e-3
+        avg_s = gemm_s / max(1, launches)
+        # flops the kernels EXECUTE: with Z = I, ZL is triangular and the banded kernel skips its
+        # all-zero K tiles (dgemm_band.h), so this is about half the dense 2 n Q C of SURVEY 8(d)
+        executed = prof["fwd_flops"] * prof["fwd_n"] + prof["bwd_flops"] * prof["bwd_n"]
+        achieved = executed / gemm_s / 1e12 if launches else 0.0
+        dense_equiv = prof["dense_flops"] * launches / gemm_s / 1e12 if launches else 0.0
         traffic = None
         pj = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if os.path.exists(pj) and n == CFG["n"] and C == CFG["chains_per_gpu"]:
             try:
-                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pj)).get("hbm_bytes_per_launch_%s" % prof["operator"])
             except Exception:
                 traffic = None
         line = {
@@ -173,11 +177,19 @@ def main():
                                    % (n, C, cfg["hmc_warmup"], cfg["max_steps"], cfg["theta_maxfun"]),
                        "n": n, "Q": n, "m_per_gpu": C, "m_total": C * world, "parallelism": "chains x%d" % world,
                        "accept_rate": res["accept_rate"], "leapfrog_steps_last_iter": res["leapfrog_total"]},
-            "roofline": {"bound": "mfma", "kernel": "dgemm_mfma_kernel (HMC forward / backward n x Q x C product)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "dgemm_%s_kernel (HMC forward / backward n x Q x C product, FP64 MFMA)"
+                                   % ("band" if prof["operator"] == "banded" else "dlds"),
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "launches": launches, "avg_launch_ms": avg_s * 1e3,
-                         "gemm_share_of_step": (prof["fwd_ms"] + prof["bwd_ms"]) * 1e-3 / dt},
+                         "flops_per_launch_executed": executed / max(1, launches),
+                         "flops_per_launch_dense_2nQC": prof["dense_flops"],
+                         "dense_equivalent_tflops": dense_equiv,
+                         "note": "achieved = flops actually executed / kernel time; the banded kernel skips the "
+                                 "structurally zero K tiles of the triangular ZL (Z = I), dense_equivalent_tflops "
+                                 "prices the same launches at SURVEY 8(d)'s dense 2nQC",
+                         "gemm_share_of_step": gemm_s / dt},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -244,9 +244,10 @@ class Context:
                     accept_rate=d.accept_rate, mean_e=d.mean_e, leapfrog_total=d.leapfrog_total)
 
     def profile(self, enable=True, reset=False):
-        out = np.zeros(4)
+        out = np.zeros(8)
         _lib.check(_lib.lib().glmmr_mcml_ctx_profile(self._h, int(enable), int(reset), _p(out)))
-        return dict(fwd_ms=out[0], fwd_n=int(out[1]), bwd_ms=out[2], bwd_n=int(out[3]))
+        return dict(fwd_ms=out[0], fwd_n=int(out[1]), bwd_ms=out[2], bwd_n=int(out[3]), fwd_flops=out[4],
+                    bwd_flops=out[5], dense_flops=out[6], operator=("dense", "banded", "sparse")[int(out[7])])
 
 
 def _problem(cov, data, eff_range, Z, X, y, family, link):

@@ -298,12 +298,25 @@ extern "C" int glmmr_mcml_sample_cols(int m, int chains)
     return chains * ((m + chains - 1) / chains);
 }
 
-// kernel timing (HIP events on the context's stream).  out: [fwd_ms, fwd_count, bwd_ms, bwd_count]
-extern "C" int glmmr_mcml_ctx_profile(glmmr_mcml_ctx* h, int enable, int reset, double* out4)
+// kernel timing (HIP events on the context's stream).
+// out8: [fwd_ms, fwd_count, bwd_ms, bwd_count, executed flops per forward launch, per backward
+// launch, dense flops per launch (2 n Q C), operator kind (0 dense GEMM, 1 banded GEMM, 2 sparse)]
+extern "C" int glmmr_mcml_ctx_profile(glmmr_mcml_ctx* h, int enable, int reset, double* out8)
 {
     MCML_REQUIRE(h, "profile: null context");
-    KernelProf& p = h->c.prof;
-    if (out4) { out4[0] = p.ms[0]; out4[1] = (double)p.cnt[0]; out4[2] = p.ms[1]; out4[3] = (double)p.cnt[1]; }
+    Ctx& c = h->c;
+    KernelProf& p = c.prof;
+    if (out8) {
+        out8[0] = p.ms[0]; out8[1] = (double)p.cnt[0]; out8[2] = p.ms[1]; out8[3] = (double)p.cnt[1];
+        const double C = (double)c.hmc.C, dense = 2.0 * c.n * (double)c.Q * C;
+        double ff = dense, fb = dense, kind = 0;
+        if (c.sp.active) { ff = fb = 2.0 * (double)c.sp.nnz * C; kind = 2; }
+        else {
+            if (c.band_fwd) { ff = 2.0 * 80.0 * 32.0 * (double)c.band_fwd_tiles * C; kind = 1; }
+            if (c.band_bwd) { fb = 2.0 * 80.0 * 32.0 * (double)c.band_bwd_tiles * C; kind = 1; }
+        }
+        out8[4] = ff; out8[5] = fb; out8[6] = dense; out8[7] = kind;
+    }
     if (reset) for (int i = 0; i < 4; ++i) { p.ms[i] = 0; p.cnt[i] = 0; }
     p.on = enable != 0;
     return MCML_OK;

@@ -54,10 +54,10 @@ const char* last_error();
 static inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
 static inline size_t round_up_sz(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Leading dimension used for every device matrix: a multiple of 16 doubles
-// (128 B) so that any column starts on a full cache line and 16-byte vector
+// Leading dimension used for every device matrix: a multiple of 32 doubles
+// (256 B) so that any column starts on a full cache line and 16-byte vector
 // loads of row pairs are always aligned.
-static inline int pad_ld(int rows) { return round_up(rows < 1 ? 1 : rows, 16); }
+static inline int pad_ld(int rows) { return round_up(rows < 1 ? 1 : rows, 32); }
 
 // Owning device allocation.
 struct DevBuf {

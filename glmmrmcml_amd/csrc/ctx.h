@@ -92,6 +92,9 @@ struct Ctx {
 
     // model state
     DevMat L, ZL, ZLT;          // Q x Q lower factor of D; n x Q; Q x n
+    DevBuf kr_fwd, kr_bwd;      // nonzero K-tile range of every 80-row band of ZL / ZLT (dgemm_band.h)
+    bool band_fwd = false, band_bwd = false;   // the structural zeros are worth skipping
+    long band_fwd_tiles = 0, band_bwd_tiles = 0;   // sum over bands of the K tiles (of 32) actually multiplied
     DevBuf xb;                  // n
     bool have_L = false;
 

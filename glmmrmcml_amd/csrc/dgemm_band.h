@@ -1,0 +1,205 @@
+// dgemm_band.h -- the HMC products with structural-zero skipping.
+//
+// For the geospatial designs Z = I, so ZL = L is lower triangular (and ZL' upper): half of
+// the K tiles a dense GEMM multiplies are exactly zero.  More generally, whenever the rows of
+// ZL (or ZL') touch only a range of columns, the products outside that range contribute
+// nothing.  When L is refreshed, k_band_ranges records for every 80-row band of the A operand
+// the first and last K tile that holds a nonzero; this kernel then runs each band's K loop
+// over that range only.
+//
+// Load balance: a workgroup owns TWO bands of one column tile, band p and its mirror
+// nbands-1-p, processed back to back, so for a triangular operand every workgroup executes the
+// same number of K steps.  63 bands x 8 column tiles -> 32 x 8 = 256 workgroups (one per CU)
+// for the 5000 x 1024 products.
+//
+// Same direct-to-LDS machinery as dgemm_dlds.h: 80 x 128 tile, 8 waves (each a 80 x 16 strip =
+// 5 x 1 v_mfma_f64_16x16x4 tiles), K step 32, 3-stage LDS ring (156 KB), counted vmcnt + raw
+// barriers.  The A image [k][80 doubles] has 640-byte rows = 32 banks mod 64, so the two
+// 16-lane halves of a ds_read_b64 (rows k, k+1) are conflict-free without a swizzle.
+// Skipping exact zeros does not change any sum (0*x adds nothing for finite x), so results
+// are identical to the dense kernels'.
+#pragma once
+#include "dgemm_dlds.h"
+
+namespace mcml {
+
+constexpr int BD_BM = 80, BD_BN = 128, BD_BK = 32, BD_STAGES = 3;
+constexpr int BD_A_BYTES = BD_BK * BD_BM * 8;      // 20480: 20 chunks of 1 KiB
+constexpr int BD_B_BYTES = BD_BK * BD_BN * 8;      // 32768: 32 chunks
+constexpr int BD_STAGE_BYTES = BD_A_BYTES + BD_B_BYTES;
+constexpr size_t BD_LDS_BYTES = (size_t)BD_STAGES * BD_STAGE_BYTES;   // 159744
+constexpr int BD_NA = 3, BD_NB = 4, BD_PER_TILE = BD_NA + BD_NB;      // LDS-DMA pieces per wave per tile
+
+struct BandP {
+    GemmP g;
+    const int* krange;     // [2*band] first K tile, [2*band+1] one past the last (units of BD_BK)
+    int nbands;
+};
+
+// first / last nonzero K tile of every 80-row band of A (M x K, column-major)
+static __global__ __launch_bounds__(256) void k_band_ranges(const double* A, int lda, int M, int K, int* krange)
+{
+    __shared__ int smin[256], smax[256];
+    const int band = blockIdx.x, r0 = band * BD_BM;
+    const int rows = (M - r0 < BD_BM) ? (M - r0) : BD_BM;
+    int kmin = 1 << 30, kmax = -1;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const double* col = A + r0 + (size_t)k * lda;
+        bool nz = false;
+        for (int r = 0; r < rows; ++r) nz |= (col[r] != 0.0);
+        if (nz) { kmin = min(kmin, k); kmax = max(kmax, k); }
+    }
+    smin[threadIdx.x] = kmin; smax[threadIdx.x] = kmax;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            smin[threadIdx.x] = min(smin[threadIdx.x], smin[threadIdx.x + o]);
+            smax[threadIdx.x] = max(smax[threadIdx.x], smax[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (smax[0] < 0) { krange[2 * band] = 0; krange[2 * band + 1] = 0; }
+        else { krange[2 * band] = smin[0] / BD_BK; krange[2 * band + 1] = smax[0] / BD_BK + 1; }
+    }
+}
+
+template <class Epi>
+__global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
+{
+    const GemmP& p = bp.g;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lk = lane >> 4;
+
+    // XCD-aware map over (band pair, column tile)
+    const int npairs = (bp.nbands + 1) >> 1;
+    const int nblk = npairs * p.gn;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int pb = nid / p.gn, bj = nid - pb * p.gn;
+    const int n0 = bj * BD_BN;
+
+    // B pieces do not depend on the band: 32 chunks, chunk c -> (kp = c >> 1, half = c & 1)
+    const double* pb0[BD_NB]; int lb[BD_NB];
+#pragma unroll
+    for (int s = 0; s < BD_NB; ++s) {
+        const int c = wave + 8 * s;
+        const int kp = c >> 1, n = ((c & 1) << 6) + lane;
+        int gn = n0 + n;
+        if (gn >= p.N) gn = 0;
+        pb0[s] = p.B + 2 * kp + (size_t)gn * p.ldb;
+        lb[s] = BD_A_BYTES + c * 1024;
+    }
+    const size_t stepA = (size_t)BD_BK * p.lda;
+
+    for (int pass = 0; pass < 2; ++pass) {
+        const int band = pass == 0 ? pb : bp.nbands - 1 - pb;
+        if (pass == 1 && band <= pb) break;                 // odd band count: the middle band runs once
+        const int m0 = band * BD_BM;
+        const int kt0 = bp.krange[2 * band], kt1 = bp.krange[2 * band + 1];
+
+        const double* pa[BD_NA]; int la[BD_NA];
+#pragma unroll
+        for (int s = 0; s < BD_NA; ++s) {
+            int c = wave + 8 * s;
+            if (c >= 20) c = wave + 8;                      // waves 4-7 repeat a chunk: uniform vmcnt
+            const int o = c * 1024 + lane * 16;
+            const int k = o / (BD_BM * 8), m = (o - k * BD_BM * 8) >> 3;
+            int gm = m0 + m;
+            if (gm >= p.M) gm = 0;
+            pa[s] = p.A + gm + (size_t)(kt0 * BD_BK + k) * p.lda;
+            la[s] = c * 1024;
+        }
+        const double* pbb[BD_NB];
+#pragma unroll
+        for (int s = 0; s < BD_NB; ++s) pbb[s] = pb0[s] + (size_t)kt0 * BD_BK;
+
+        auto issue = [&](int stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            char* base = lds + stage * BD_STAGE_BYTES;
+#pragma unroll
+            for (int s = 0; s < BD_NA; ++s) {
+                __builtin_amdgcn_global_load_lds(pa[s], (lds_ptr_t)(base + la[s]), 16, 0, 0);
+                pa[s] += stepA;
+            }
+#pragma unroll
+            for (int s = 0; s < BD_NB; ++s) {
+                __builtin_amdgcn_global_load_lds(pbb[s], (lds_ptr_t)(base + lb[s]), 16, 0, 0);
+                pbb[s] += BD_BK;
+            }
+#else
+            (void)stage; (void)stepA;
+#endif
+        };
+        auto wait_leave = [&](int tiles) {
+            static_assert(BD_PER_TILE == 7, "vmcnt immediates below");
+            if (tiles >= 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            else if (tiles == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+
+        d4 acc[5][1];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i][0] = d4{0.0, 0.0, 0.0, 0.0};
+
+        const int nk = kt1 - kt0;
+        if (nk > 0) {
+            int issued = 0;
+            for (; issued < BD_STAGES - 1 && issued < nk; ++issued) issue(issued);
+            wait_leave(issued - 1);
+            __builtin_amdgcn_s_barrier();
+            int st = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                if (issued < nk) {
+                    int sn = st + BD_STAGES - 1; if (sn >= BD_STAGES) sn -= BD_STAGES;
+                    issue(sn);
+                    ++issued;
+                }
+                const double* as = reinterpret_cast<const double*>(lds + st * BD_STAGE_BYTES);
+                const double* bs = reinterpret_cast<const double*>(lds + st * BD_STAGE_BYTES + BD_A_BYTES);
+#pragma unroll
+                for (int ks = 0; ks < BD_BK / 4; ++ks) {
+                    const int kk = 4 * ks + lk;
+                    double a[5];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) a[i] = as[kk * BD_BM + 16 * i + l15];
+                    const double b = bs[((kk >> 1) * BD_BN + wave * 16 + l15) * 2 + (kk & 1)];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+                        acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a[i], acc[i][0], 0, 0, 0);
+                }
+                wait_leave(issued - kt - 2);
+                __builtin_amdgcn_s_barrier();
+                st = st + 1; if (st >= BD_STAGES) st = 0;
+            }
+        }
+        epi(acc, m0, n0 + wave * 16, lane, p.M, p.N, band);
+        // the next band's first LDS-DMA may overwrite a stage another wave is still reading
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+template <class Epi>
+static inline int launch_gemm_band(hipStream_t s, int M, int N, int K, const double* A, int lda,
+                                   const double* B, int ldb, const int* krange, const Epi& epi)
+{
+    BandP bp;
+    bp.g = GemmP{M, N, K, A, lda, B, ldb, 0, (N + BD_BN - 1) / BD_BN, 0, 0};
+    bp.krange = krange;
+    bp.nbands = (M + BD_BM - 1) / BD_BM;
+    const int npairs = (bp.nbands + 1) / 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MCML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dgemm_band_kernel<Epi>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)BD_LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dgemm_band_kernel<Epi>), dim3(npairs * bp.g.gn), dim3(512), BD_LDS_BYTES, s, bp, epi);
+    MCML_HIP(hipGetLastError());
+    return MCML_OK;
+}
+
+}  // namespace mcml

@@ -25,21 +25,28 @@
 
 namespace mcml {
 
-constexpr int DL_BM = 160, DL_BN = 128, DL_BK = 16;
-#ifndef DL_STAGES_N
-#define DL_STAGES_N 3
-#endif
-constexpr int DL_STAGES = DL_STAGES_N;      // LDS ring: DL_STAGES - 1 tiles in flight
-constexpr int DL_A_BYTES = DL_BK * DL_BM * 8;          // 20480 = 20 chunks of 1 KiB
-constexpr int DL_B_BYTES = DL_BK * DL_BN * 8;          // 16384 = 16 chunks
-constexpr int DL_STAGE_BYTES = DL_A_BYTES + DL_B_BYTES;
-constexpr size_t DL_LDS_BYTES = (size_t)DL_STAGES * DL_STAGE_BYTES;   // 110592
+constexpr int DL_BM = 160, DL_BN = 128;
+// (K step, ring stages): (16, 3) keeps two tiles in flight in 108 KB; (32, 2) halves the
+// barriers with one tile in flight in 144 KB
+template <int BK, int STAGES>
+struct DlCfg {
+    static constexpr int A_BYTES = BK * DL_BM * 8;         // BK=16: 20 chunks of 1 KiB; 32: 40
+    static constexpr int B_BYTES = BK * DL_BN * 8;         // BK=16: 16 chunks; 32: 32
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE_BYTES;
+    static constexpr int A_CHUNKS = A_BYTES / 1024, B_CHUNKS = B_BYTES / 1024;
+    static constexpr int NA = (A_CHUNKS + 7) / 8, NB = B_CHUNKS / 8;   // LDS-DMA pieces per wave per tile
+    static constexpr int PER_TILE = NA + NB;
+};
+constexpr int DL_BK = 16;     // K padding granule the callers provide (a multiple of it serves both)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <class Epi>
+template <int BK, int STAGES, class Epi>
 __global__ __launch_bounds__(512) void dgemm_dlds_kernel(GemmP p, Epi epi)
 {
+    using Cfg = DlCfg<BK, STAGES>;
+    constexpr int DL_A_BYTES = Cfg::A_BYTES, DL_STAGE_BYTES = Cfg::STAGE_BYTES, DL_STAGES = STAGES;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     char* lds = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -55,11 +62,11 @@ __global__ __launch_bounds__(512) void dgemm_dlds_kernel(GemmP p, Epi epi)
     // ---- per-lane source pointers of this wave's LDS-DMA pieces (advance by a constant per K step)
     // A: chunks c = wave, wave + 8, and wave + 16 for waves 0-3 (waves 4-7 repeat their second
     // chunk: identical bytes to the same place, keeps the vmcnt bookkeeping uniform)
-    const double* pa[3]; int la[3];
+    const double* pa[Cfg::NA]; int la[Cfg::NA];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < Cfg::NA; ++s) {
         int c = wave + 8 * s;
-        if (c >= 20) c = wave + 8;
+        if (c >= Cfg::A_CHUNKS) c = wave + 8;
         const int o = c * 1024 + lane * 16;               // byte offset inside the A image
         const int k = o / (DL_BM * 8), pos = (o - k * DL_BM * 8) >> 3;      // position (doubles) in row k
         const int blk = pos >> 4, within = pos & 15;
@@ -69,9 +76,9 @@ __global__ __launch_bounds__(512) void dgemm_dlds_kernel(GemmP p, Epi epi)
         pa[s] = p.A + gm + (size_t)k * p.lda;
         la[s] = c * 1024;
     }
-    const double* pb[2]; int lb[2];
+    const double* pb[Cfg::NB]; int lb[Cfg::NB];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < Cfg::NB; ++s) {
         const int c = wave + 8 * s;                        // 16 chunks: kp = c >> 1, half = c & 1
         const int kp = c >> 1, n = ((c & 1) << 6) + lane;
         int gn = n0 + n;
@@ -79,20 +86,26 @@ __global__ __launch_bounds__(512) void dgemm_dlds_kernel(GemmP p, Epi epi)
         pb[s] = p.B + 2 * kp + (size_t)gn * p.ldb;
         lb[s] = DL_A_BYTES + c * 1024;
     }
-    const size_t stepA = (size_t)DL_BK * p.lda;
+    const size_t stepA = (size_t)BK * p.lda;
 
     auto issue = [&](int stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (the host pass must not see the amdgcn builtin in this template-dependent context: clang
+        // would silently drop the whole kernel stub)
         char* base = lds + stage * DL_STAGE_BYTES;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < Cfg::NA; ++s) {
             __builtin_amdgcn_global_load_lds(pa[s], (lds_ptr_t)(base + la[s]), 16, 0, 0);
             pa[s] += stepA;
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < Cfg::NB; ++s) {
             __builtin_amdgcn_global_load_lds(pb[s], (lds_ptr_t)(base + lb[s]), 16, 0, 0);
-            pb[s] += DL_BK;
+            pb[s] += BK;
         }
+#else
+        (void)stage; (void)stepA;
+#endif
     };
 
     d4 acc[5][2];
@@ -106,7 +119,7 @@ __global__ __launch_bounds__(512) void dgemm_dlds_kernel(GemmP p, Epi epi)
         const double* as = reinterpret_cast<const double*>(lds + stage * DL_STAGE_BYTES);
         const double* bs = reinterpret_cast<const double*>(lds + stage * DL_STAGE_BYTES + DL_A_BYTES);
 #pragma unroll
-        for (int ks = 0; ks < DL_BK / 4; ++ks) {
+        for (int ks = 0; ks < BK / 4; ++ks) {
             const int kk = 4 * ks + lk;
             double a[5], b[2];
 #pragma unroll
@@ -121,13 +134,19 @@ __global__ __launch_bounds__(512) void dgemm_dlds_kernel(GemmP p, Epi epi)
         }
     };
 
-    const int nk = (p.K + DL_BK - 1) / DL_BK;              // operands are zero-padded to nk * 16
-    // each wave issues 5 LDS-DMA pieces per tile; "leave t tiles in flight" = vmcnt(5 t)
+    const int nk = (p.K + BK - 1) / BK;                    // operands are zero-padded to nk * BK
+    // each wave issues PER_TILE LDS-DMA pieces per tile; "leave t tiles in flight" = vmcnt(PER_TILE t)
     auto wait_leave = [&](int tiles) {
-        if (tiles >= 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-        else if (tiles == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if (tiles == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_assert(Cfg::PER_TILE == 5 || Cfg::PER_TILE == 9, "vmcnt immediates below");
+        if constexpr (Cfg::PER_TILE == 5) {
+            if (tiles >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (tiles == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (tiles >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else if (tiles == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     };
     int issued = 0;
     for (; issued < DL_STAGES - 1 && issued < nk; ++issued) issue(issued);
@@ -153,9 +172,24 @@ __global__ __launch_bounds__(512) void dgemm_dlds_kernel(GemmP p, Epi epi)
 static inline bool dlds_applicable(int M, int N, int K, const double* A, int lda, int a_cols_alloc,
                                    const double* B, int ldb)
 {
-    const int kpad = round_up(K, DL_BK);
+    const int kpad = round_up(K, 32);      // serves both K steps
     return M >= 1 && N >= 1 && K >= 1 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
            (lda & 1) == 0 && (ldb & 1) == 0 && lda >= M && ldb >= kpad && a_cols_alloc >= kpad;
+}
+
+template <int BK, int STAGES, class Epi>
+static inline int launch_gemm_dlds_cfg(hipStream_t s, const GemmP& p, const Epi& epi)
+{
+    using Cfg = DlCfg<BK, STAGES>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MCML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dgemm_dlds_kernel<BK, STAGES, Epi>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dgemm_dlds_kernel<BK, STAGES, Epi>), dim3(p.gm * p.gn), dim3(512), Cfg::LDS_BYTES, s, p, epi);
+    MCML_HIP(hipGetLastError());
+    return MCML_OK;
 }
 
 template <class Epi>
@@ -163,15 +197,9 @@ static inline int launch_gemm_dlds(hipStream_t s, int M, int N, int K, const dou
                                    const double* B, int ldb, const Epi& epi)
 {
     GemmP p{M, N, K, A, lda, B, ldb, (M + DL_BM - 1) / DL_BM, (N + DL_BN - 1) / DL_BN, 0, 0};
-    static bool attr_set = false;
-    if (!attr_set) {
-        MCML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dgemm_dlds_kernel<Epi>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)DL_LDS_BYTES));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((dgemm_dlds_kernel<Epi>), dim3(p.gm * p.gn), dim3(512), DL_LDS_BYTES, s, p, epi);
-    MCML_HIP(hipGetLastError());
-    return MCML_OK;
+    static const int variant = getenv("GLMMR_MCML_DLDS") ? atoi(getenv("GLMMR_MCML_DLDS")) : 0;
+    if (variant == 1) return launch_gemm_dlds_cfg<32, 2, Epi>(s, p, epi);
+    return launch_gemm_dlds_cfg<16, 3, Epi>(s, p, epi);
 }
 
 }  // namespace mcml

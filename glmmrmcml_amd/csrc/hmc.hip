@@ -18,6 +18,7 @@
 #include "ctx.h"
 #include "dgemm_mfma.h"
 #include "dgemm_dlds.h"
+#include "dgemm_band.h"
 #include "glm.h"
 #include "reduce.h"
 #include "rng.h"
@@ -369,7 +370,9 @@ static int hmc_forward(Ctx& c, const double* X, int ldx)
         hipLaunchKernelGGL((k_sp_forward<EpiForward>), dim3((c.n + 255) / 256, gy), dim3(256), 0, c.stream, c.n, h.C,
                            c.sp.W, c.sp.ell_col.as<int>(), c.sp.ell_val.d(), X, ldx, epi);
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
-    } else if (use_dlds() && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
+    } else if (c.band_fwd && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
+        rc = launch_gemm_band(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, c.kr_fwd.as<int>(), epi);
+    else if (use_dlds() && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
         rc = launch_gemm_dlds(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
     else
         rc = launch_gemm<false>(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
@@ -396,7 +399,9 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
                            c.sp.csr_ptr.as<int>(), c.sp.csr_i.as<int>(), c.sp.csr_pos.as<int>(), c.sp.ell_val.d(),
                            h.S.d(), h.S.ld, epi);
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
-    } else if (use_dlds() && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
+    } else if (c.band_bwd && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
+        rc = launch_gemm_band(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, c.kr_bwd.as<int>(), epi);
+    else if (use_dlds() && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
         rc = launch_gemm_dlds(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
     else
         rc = launch_gemm<false>(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);

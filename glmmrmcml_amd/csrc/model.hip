@@ -11,6 +11,7 @@
 // matrix, also as padded-CSR rows so that Z u and Z L are row gathers.
 #include "ctx.h"
 #include "dgemm_mfma.h"
+#include "dgemm_band.h"
 #include "glm.h"
 #include "reduce.h"
 
@@ -228,8 +229,8 @@ int model_update_L(Ctx& c)
     c.sp.active = false;
     // K-padding columns (zero) so that the direct-to-LDS GEMM needs no K guards
     if (c.ZL.rows != c.n || c.ZL.cols != c.Q || !c.ZL.d()) {
-        MCML_TRY(c.ZL.alloc(c.n, c.Q, 16));
-        MCML_TRY(c.ZLT.alloc(c.Q, c.n, 16));
+        MCML_TRY(c.ZL.alloc(c.n, c.Q, 32));
+        MCML_TRY(c.ZLT.alloc(c.Q, c.n, 32));
         MCML_HIP(hipMemsetAsync(c.ZL.d(), 0, sizeof(double) * (size_t)c.ZL.ld * c.ZL.cols_alloc, c.stream));
         MCML_HIP(hipMemsetAsync(c.ZLT.d(), 0, sizeof(double) * (size_t)c.ZLT.ld * c.ZLT.cols_alloc, c.stream));
     }
@@ -242,6 +243,29 @@ int model_update_L(Ctx& c)
     hipLaunchKernelGGL(k_transpose, dim3((c.n + 31) / 32, (c.Q + 31) / 32), dim3(256), 0, c.stream, c.ZL.d(),
                        c.ZL.ld, c.n, c.Q, c.ZLT.d(), c.ZLT.ld);
     MCML_HIP(hipGetLastError());
+    // structural zeros of ZL / ZL' (triangular when Z = I): record each 80-row band's range of
+    // nonzero K tiles; the banded kernel is used when it skips at least a fifth of the tiles
+    c.band_fwd = c.band_bwd = false;
+    const char* env = getenv("GLMMR_MCML_GEMM");
+    if (!(env && (!strcmp(env, "reg") || !strcmp(env, "dlds")))) {
+        auto ranges = [&](const DevMat& A, int M, int K, DevBuf& kr, bool& use, long& ntiles) -> int {
+            const int nb = (M + BD_BM - 1) / BD_BM;
+            MCML_TRY(kr.ensure(sizeof(int) * 2 * (size_t)nb));
+            hipLaunchKernelGGL(k_band_ranges, dim3(nb), dim3(256), 0, c.stream, A.d(), A.ld, M, K, kr.as<int>());
+            MCML_HIP(hipGetLastError());
+            std::vector<int> h(2 * (size_t)nb);
+            MCML_HIP(hipMemcpyAsync(h.data(), kr.p, sizeof(int) * h.size(), hipMemcpyDeviceToHost, c.stream));
+            MCML_HIP(hipStreamSynchronize(c.stream));
+            long tiles = 0;
+            for (int b = 0; b < nb; ++b) tiles += h[2 * b + 1] - h[2 * b];
+            const long dense = (long)nb * ((K + BD_BK - 1) / BD_BK);
+            use = (env && !strcmp(env, "band")) || tiles * 5 <= dense * 4;
+            ntiles = tiles;
+            return MCML_OK;
+        };
+        MCML_TRY(ranges(c.ZL, c.n, c.Q, c.kr_fwd, c.band_fwd, c.band_fwd_tiles));
+        MCML_TRY(ranges(c.ZLT, c.Q, c.n, c.kr_bwd, c.band_bwd, c.band_bwd_tiles));
+    }
     return MCML_OK;
 }
 

@@ -139,8 +139,10 @@ typedef struct glmmr_mcml_ext {
 int glmmr_mcml_sample_cols(int m, int chains);
 int glmmr_mcml_ctx_ncols(glmmr_mcml_ctx* ctx);
 /* HIP-event timing of the sampler's two GEMMs on the context's stream.
- * out4 (nullable) = [forward ms, forward launches, backward ms, backward launches] so far */
-int glmmr_mcml_ctx_profile(glmmr_mcml_ctx* ctx, int enable, int reset, double* out4);
+ * out8 (nullable) = [forward ms, forward launches, backward ms, backward launches so far,
+ * executed flops per forward / per backward launch, dense flops per launch (2 n Q C),
+ * operator kind: 0 dense GEMM, 1 banded GEMM (structural zeros of ZL skipped), 2 sparse] */
+int glmmr_mcml_ctx_profile(glmmr_mcml_ctx* ctx, int enable, int reset, double* out8);
 int glmmr_mcml_ctx_npar(glmmr_mcml_ctx* ctx);
 
 /* The same drivers on a resident context (what bench.py times). */

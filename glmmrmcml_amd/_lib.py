@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libglmmr_mcml_hip.so")
+# GLMMR_MCML_LIB: developer override for A/B timing of two builds of the same library
+LIB_PATH = os.environ.get("GLMMR_MCML_LIB") or os.path.join(_HERE, "libglmmr_mcml_hip.so")
 _lib = None
 
 

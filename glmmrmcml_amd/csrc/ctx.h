@@ -118,6 +118,15 @@ struct Ctx {
     DevBuf reduce_buf;          // doubles handed to the reduce hook
     DevBuf scratch;             // short-lived per-call scratch
 
+    // side stream + events for the Cholesky look-ahead (mvn.hip potrf_blocked)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_col = nullptr, ev_leaf = nullptr;
+    ~Ctx() {
+        if (ev_col) (void)hipEventDestroy(ev_col);
+        if (ev_leaf) (void)hipEventDestroy(ev_leaf);
+        if (aux) (void)hipStreamDestroy(aux);
+    }
+
     int sync() { MCML_HIP(hipStreamSynchronize(stream)); return MCML_OK; }
 };
 

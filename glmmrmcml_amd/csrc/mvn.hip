@@ -469,24 +469,54 @@ static int potrf_rec(Ctx& c, double* A0, int lda, int off, int n)
 }
 
 // Right-looking variant: one 128-wide panel at a time -- leaf (factor + invert the diagonal
-// block in LDS), panel TRSM as a GEMM against the inverted block, SYRK of the whole
-// trailing matrix.  3 launches per panel instead of the recursion's many small ones.
-static bool chol_blocked()
+// block in LDS), panel TRSM as a GEMM against the inverted block, SYRK of the trailing matrix.
+//
+// Look-ahead: the leaf is a single-workgroup, latency-bound kernel (~90 us) and the late
+// panels' GEMMs are small, so running them back to back leaves the chip idle most of the
+// time.  The trailing update is therefore split: the next panel's 128 columns are updated
+// first, the next leaf then runs on a high-priority side stream while the main stream updates
+// the rest of the trailing matrix (columns the leaf never touches).
+//   GLMMR_MCML_CHOL=rec    : the recursive variant;  =nola : this one without look-ahead
+static int chol_mode()
 {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("GLMMR_MCML_CHOL"); v = (e && !strcmp(e, "rec")) ? 0 : 1; }
-    return v == 1;
+    if (v < 0) {
+        const char* e = getenv("GLMMR_MCML_CHOL");
+        v = (e && !strcmp(e, "rec")) ? 0 : (e && !strcmp(e, "nola")) ? 2 : 1;
+    }
+    return v;
+}
+static bool chol_blocked() { return chol_mode() != 0; }
+
+static int lookahead_setup(Ctx& c)
+{
+    if (c.aux) return MCML_OK;
+    int lo = 0, hi = 0;
+    MCML_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    MCML_HIP(hipStreamCreateWithPriority(&c.aux, hipStreamNonBlocking, hi));
+    MCML_HIP(hipEventCreateWithFlags(&c.ev_col, hipEventDisableTiming));
+    MCML_HIP(hipEventCreateWithFlags(&c.ev_leaf, hipEventDisableTiming));
+    return MCML_OK;
 }
 
 static int potrf_blocked(Ctx& c, double* A, int lda, int n)
 {
+    // look-ahead pays while the rest of the trailing update is at least as long as a leaf
+    static const int la_min = getenv("GLMMR_MCML_LA_MIN") ? atoi(getenv("GLMMR_MCML_LA_MIN")) : 2048;
+    const bool la_any = chol_mode() == 1 && n - 2 * CHOL_NB >= la_min;
+    if (la_any) MCML_TRY(lookahead_setup(c));
+    int* errflag = c.scalars.as<int>() + 32;
+    auto leaf = [&](hipStream_t s, int k, int nb) -> int {
+        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), POTRF_LDS, s, A + k + (size_t)k * lda, lda, nb,
+                           c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB, errflag);
+        MCML_HIP(hipGetLastError());
+        return MCML_OK;
+    };
+    MCML_TRY(leaf(c.stream, 0, n < CHOL_NB ? n : CHOL_NB));
     for (int k = 0; k < n; k += CHOL_NB) {
         const int nb = (n - k < CHOL_NB) ? n - k : CHOL_NB;
         double* A11 = A + k + (size_t)k * lda;
-        double* Linv = c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB;
-        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), POTRF_LDS, c.stream, A11, lda, nb, Linv,
-                           c.scalars.as<int>() + 32);
-        MCML_HIP(hipGetLastError());
+        const double* Linv = c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB;
         const int rem = n - k - nb;
         if (rem <= 0) break;
         double* A21 = A11 + nb;
@@ -495,8 +525,28 @@ static int potrf_blocked(Ctx& c, double* A, int lda, int n)
             MCML_TRY(launch_gemm<true>(c.stream, rem, nb, nb, A21, lda, Linv, CHOL_NB, epi, false, 1));
         }
         double* A22 = A11 + nb + (size_t)nb * lda;
-        EpiAxpby epi{A22, lda, -1.0, 1.0};
-        MCML_TRY(launch_gemm<true>(c.stream, rem, rem, nb, A21, lda, A21, lda, epi, true));
+        const int nb2 = rem < CHOL_NB ? rem : CHOL_NB;
+        const bool la = la_any && rem - nb2 >= la_min;
+        if (!la) {
+            EpiAxpby epi{A22, lda, -1.0, 1.0};
+            MCML_TRY(launch_gemm<true>(c.stream, rem, rem, nb, A21, lda, A21, lda, epi, true));
+            MCML_TRY(leaf(c.stream, k + nb, nb2));
+            continue;
+        }
+        {   // the next panel's columns (its upper triangle inside the diagonal block is scratch)
+            EpiAxpby epi{A22, lda, -1.0, 1.0};
+            MCML_TRY(launch_gemm<true>(c.stream, rem, nb2, nb, A21, lda, A21, lda, epi));
+        }
+        MCML_HIP(hipEventRecord(c.ev_col, c.stream));
+        MCML_HIP(hipStreamWaitEvent(c.aux, c.ev_col, 0));
+        MCML_TRY(leaf(c.aux, k + nb, nb2));
+        MCML_HIP(hipEventRecord(c.ev_leaf, c.aux));
+        const int rem2 = rem - nb2;
+        if (rem2 > 0) {
+            EpiAxpby epi{A22 + nb2 + (size_t)nb2 * lda, lda, -1.0, 1.0};
+            MCML_TRY(launch_gemm<true>(c.stream, rem2, rem2, nb, A21 + nb2, lda, A21 + nb2, lda, epi, true));
+        }
+        MCML_HIP(hipStreamWaitEvent(c.stream, c.ev_leaf, 0));
     }
     return MCML_OK;
 }

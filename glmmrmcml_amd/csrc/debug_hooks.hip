@@ -1,6 +1,7 @@
 // debug_hooks.hip -- C-ABI test/bench hooks for the GEMM building block
 // (declared in include/glmmr_mcml_c.h under "test hooks").
 #include "dgemm_mfma.h"
+#include "dgemm_dl.h"
 
 using namespace mcml;
 
@@ -21,10 +22,13 @@ extern "C" int glmmr_mcml_dbg_dgemm(int M, int N, int K, const double* A, int ld
     else MCML_TRY(upload_matrix(dB, B, K, N, ldb, s));
     MCML_TRY(upload_matrix(dC, C, M, N, ldc, s));
     EpiAxpby epi{dC.d(), dC.ld, alpha, beta};
-    int rc = b_nmajor ? launch_gemm<true>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi,
-                                          lower_only != 0, force_tile)
-                      : launch_gemm<false>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi,
-                                           lower_only != 0, force_tile);
+    int rc;
+    if (force_tile >= 20)      // 20 / 21: the deep-ring direct-to-LDS kernel (dgemm_dl.h), 128x128 / 64x128 tiles
+        rc = b_nmajor ? launch_gemm_dl<true>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, lower_only != 0, force_tile - 19)
+                      : launch_gemm_dl<false>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, lower_only != 0, force_tile - 19);
+    else
+        rc = b_nmajor ? launch_gemm<true>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, lower_only != 0, force_tile)
+                      : launch_gemm<false>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, lower_only != 0, force_tile);
     MCML_TRY(rc);
     MCML_TRY(download_matrix(C, ldc, dC.d(), dC.ld, M, N, s));
     return MCML_OK;
@@ -52,6 +56,9 @@ extern "C" int glmmr_mcml_dbg_dgemm_bench(int M, int N, int K, int b_nmajor, int
     MCML_TRY(upload_matrix(dC, hC.data(), M, N, M, s));
     EpiAxpby epi{dC.d(), dC.ld, 1.0, 0.0};
     auto go = [&]() {
+        if (force_tile >= 20)
+            return b_nmajor ? launch_gemm_dl<true>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, false, force_tile - 19)
+                            : launch_gemm_dl<false>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, false, force_tile - 19);
         return b_nmajor ? launch_gemm<true>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, false, force_tile)
                         : launch_gemm<false>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, false, force_tile);
     };

@@ -47,11 +47,14 @@ static ChainArrays chain_arrays(const HmcState& h)
 
 // ------------------------------------------------------------------ GEMM epilogues
 // forward: MU = xb + acc ; S = score(y, MU)          (mcmlmodel.h:160-162,169-276)
+// store_mu = 0: inside a leapfrog trajectory only the score feeds the next product; the linear
+// predictor itself is read (by k_hmc_accept) after the LAST step only, so its 8 n C bytes per
+// launch are not written
 struct EpiForward {
-    double* MU; double* S; int ld; const double* xb; const double* y; int flink;
+    double* MU; double* S; int ld; const double* xb; const double* y; int flink; int store_mu;
     __device__ __forceinline__ void elem(int m, int n, double accv) const {
         const double mu = xb[m] + accv;
-        MU[m + (size_t)n * ld] = mu;
+        if (store_mu) MU[m + (size_t)n * ld] = mu;
         S[m + (size_t)n * ld] = glm_score(y[m], mu, flink);
     }
     template <int TM, int TN>
@@ -69,7 +72,7 @@ struct EpiForward {
                     const int n = nB + 16 * j + (lane >> 4) + 4 * r;
                     if (n < N) {
                         const double mu = xbi + acc[i][j][r];
-                        MU[m + (size_t)n * ld] = mu;
+                        if (store_mu) MU[m + (size_t)n * ld] = mu;
                         S[m + (size_t)n * ld] = glm_score(yi, mu, flink);
                     }
                 }
@@ -90,7 +93,7 @@ struct EpiBackward {
         const double x = Xs[off];
         double g = -1.0 * x;
         g = g + post * accv;
-        G[off] = g;
+        if (mode != 1 || s + 1 >= st) G[off] = g;     // mid-trajectory gradients are never read
         if (mode == 1) {
             double rr = R[off];
             rr = rr + (en / 2) * g;
@@ -120,7 +123,7 @@ struct EpiBackward {
                     const double x = Xs[off];
                     double g = -1.0 * x;
                     g = g + post * acc[i][j][r];
-                    G[off] = g;
+                    if (mode != 1 || s + 1 >= st) G[off] = g;
                     if (mode == 1) {
                         double rr = R[off];
                         rr = rr + (en / 2) * g;
@@ -359,10 +362,10 @@ static bool use_dlds()
 }
 
 // MU = xb + ZL * X ; S = score
-static int hmc_forward(Ctx& c, const double* X, int ldx)
+static int hmc_forward(Ctx& c, const double* X, int ldx, bool store_mu = true)
 {
     HmcState& h = c.hmc;
-    EpiForward epi{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink};
+    EpiForward epi{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink, store_mu ? 1 : 0};
     const int slot = c.prof.begin(c.stream, 0);
     int rc;
     if (c.sp.active) {
@@ -476,7 +479,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         MCML_HIP(hipStreamSynchronize(c.stream));
         MCML_REQUIRE(maxs >= 1 && maxs <= o->max_steps, "hmc: step count %d out of range", maxs);
         for (int s = 0; s < maxs; ++s) {
-            MCML_TRY(hmc_forward(c, h.UP.d(), h.UP.ld));
+            MCML_TRY(hmc_forward(c, h.UP.d(), h.UP.ld, s == maxs - 1));
             MCML_TRY(hmc_backward(c, h.UP.d(), h.GRADP.d(), s, var_par, 1));
         }
         const int adapt = (it < o->warmup) && (it < o->adapt);     // mhmcmc.h:131-136

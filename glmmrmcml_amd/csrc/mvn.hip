@@ -18,6 +18,7 @@
 // bit-reproducible.
 #include "ctx.h"
 #include "dgemm_mfma.h"
+#include "dgemm_dl.h"
 #include "reduce.h"
 
 namespace mcml {
@@ -468,6 +469,20 @@ static int potrf_rec(Ctx& c, double* A0, int lda, int off, int n)
     return potrf_rec(c, A0, lda, off + n1, n2);
 }
 
+// The K = 128 panel GEMMs of the blocked factorisation / solve: deep-ring direct-to-LDS kernel
+// (dgemm_dl.h) when its contract holds, the register-staged kernel otherwise.
+//   inplace: 0 none, 1 = C aliases A (N <= 128), 2 = C aliases B (M <= 128)
+//   GLMMR_MCML_CHOL_GEMM=reg : always the register-staged kernel
+template <bool BNMAJOR>
+static int chol_gemm(hipStream_t s, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
+                     const EpiAxpby& epi, bool lower_only, int inplace)
+{
+    static const bool use_dl = !(getenv("GLMMR_MCML_CHOL_GEMM") && !strcmp(getenv("GLMMR_MCML_CHOL_GEMM"), "reg"));
+    if (use_dl && dl_applicable(M, N, K, A, lda, B, ldb, BNMAJOR))
+        return launch_gemm_dl<BNMAJOR>(s, M, N, K, A, lda, B, ldb, epi, lower_only, inplace == 2 ? 1 : 0);
+    return launch_gemm<BNMAJOR>(s, M, N, K, A, lda, B, ldb, epi, lower_only, inplace ? inplace : -1);
+}
+
 // Right-looking variant: one 128-wide panel at a time -- leaf (factor + invert the diagonal
 // block in LDS), panel TRSM as a GEMM against the inverted block, SYRK of the trailing matrix.
 //
@@ -522,20 +537,20 @@ static int potrf_blocked(Ctx& c, double* A, int lda, int n)
         double* A21 = A11 + nb;
         {
             EpiAxpby epi{A21, lda, 1.0, 0.0};
-            MCML_TRY(launch_gemm<true>(c.stream, rem, nb, nb, A21, lda, Linv, CHOL_NB, epi, false, 1));
+            MCML_TRY(chol_gemm<true>(c.stream, rem, nb, nb, A21, lda, Linv, CHOL_NB, epi, false, 1));
         }
         double* A22 = A11 + nb + (size_t)nb * lda;
         const int nb2 = rem < CHOL_NB ? rem : CHOL_NB;
         const bool la = la_any && rem - nb2 >= la_min;
         if (!la) {
             EpiAxpby epi{A22, lda, -1.0, 1.0};
-            MCML_TRY(launch_gemm<true>(c.stream, rem, rem, nb, A21, lda, A21, lda, epi, true));
+            MCML_TRY(chol_gemm<true>(c.stream, rem, rem, nb, A21, lda, A21, lda, epi, true, 0));
             MCML_TRY(leaf(c.stream, k + nb, nb2));
             continue;
         }
         {   // the next panel's columns (its upper triangle inside the diagonal block is scratch)
             EpiAxpby epi{A22, lda, -1.0, 1.0};
-            MCML_TRY(launch_gemm<true>(c.stream, rem, nb2, nb, A21, lda, A21, lda, epi));
+            MCML_TRY(chol_gemm<true>(c.stream, rem, nb2, nb, A21, lda, A21, lda, epi, false, 0));
         }
         MCML_HIP(hipEventRecord(c.ev_col, c.stream));
         MCML_HIP(hipStreamWaitEvent(c.aux, c.ev_col, 0));
@@ -544,7 +559,7 @@ static int potrf_blocked(Ctx& c, double* A, int lda, int n)
         const int rem2 = rem - nb2;
         if (rem2 > 0) {
             EpiAxpby epi{A22 + nb2 + (size_t)nb2 * lda, lda, -1.0, 1.0};
-            MCML_TRY(launch_gemm<true>(c.stream, rem2, rem2, nb, A21 + nb2, lda, A21 + nb2, lda, epi, true));
+            MCML_TRY(chol_gemm<true>(c.stream, rem2, rem2, nb, A21 + nb2, lda, A21 + nb2, lda, epi, true, 0));
         }
         MCML_HIP(hipStreamWaitEvent(c.stream, c.ev_leaf, 0));
     }
@@ -559,13 +574,13 @@ static int trsm_left_blocked(Ctx& c, const double* L, int ldl, int n, double* U,
         double* Uk = U + k;
         {
             EpiAxpby epi{Uk, ldu, 1.0, 0.0};
-            MCML_TRY(launch_gemm<false>(c.stream, nb, m, nb, Linv, CHOL_NB, Uk, ldu, epi, false, 2));
+            MCML_TRY(chol_gemm<false>(c.stream, nb, m, nb, Linv, CHOL_NB, Uk, ldu, epi, false, 2));
         }
         const int rem = n - k - nb;
         if (rem <= 0) break;
         const double* L21 = L + (k + nb) + (size_t)k * ldl;
         EpiAxpby epi{Uk + nb, ldu, -1.0, 1.0};
-        MCML_TRY(launch_gemm<false>(c.stream, rem, m, nb, L21, ldl, Uk, ldu, epi));
+        MCML_TRY(chol_gemm<false>(c.stream, rem, m, nb, L21, ldl, Uk, ldu, epi, false, 0));
     }
     return MCML_OK;
 }

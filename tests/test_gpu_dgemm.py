@@ -55,3 +55,36 @@ def test_dgemm_lower_only_leaves_upper_tiles():
     assert np.allclose(got[low], want[low], rtol=0, atol=1e-10)
     # tiles strictly above the diagonal are untouched
     assert np.array_equal(got[0:128, 640:], C0[0:128, 640:])
+
+
+# the short-K direct-to-LDS kernel of the Cholesky / TRSM panel updates (dgemm_dl.h): K % 16 == 0
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (4872, 128, 128), (1000, 1024, 128), (131, 77, 16),
+                                   (5, 3, 32), (777, 300, 256), (64, 128, 128)])
+@pytest.mark.parametrize("b_nmajor", [0, 1])
+@pytest.mark.parametrize("tile", [20, 21])
+def test_dgemm_dl_matches_numpy(M, N, K, b_nmajor, tile):
+    rng = np.random.default_rng(M * 5 + N * 11 + K)
+    A = rng.normal(size=(M, K)); Bm = rng.normal(size=(K, N)); C0 = rng.normal(size=(M, N))
+    Bdev = Bm.T.copy() if b_nmajor else Bm
+    got = _gemm(A, Bdev, C0, -1.0, 1.0, b_nmajor, tile=tile)
+    want = C0 - A @ Bm
+    bound = 1e-12 * (np.abs(A) @ np.abs(Bm) + np.abs(C0))
+    assert np.all(np.abs(got - want) <= bound)
+
+
+@pytest.mark.parametrize("tile", [20, 21])
+def test_dgemm_dl_lower_only(tile):
+    rng = np.random.default_rng(5)
+    n, k = 900, 128
+    A = rng.normal(size=(n, k)); C0 = rng.normal(size=(n, n))
+    got = _gemm(A, A, C0, -1.0, 1.0, 1, lower_only=1, tile=tile)
+    want = C0 - A @ A.T
+    low = np.tril_indices(n)
+    assert np.allclose(got[low], want[low], rtol=0, atol=1e-10)
+    assert np.array_equal(got[0:64, 768:], C0[0:64, 768:])
+
+
+def test_dgemm_dl_rejects_ragged_k():
+    from glmmrmcml_amd import _lib
+    with pytest.raises(_lib.McmlError):
+        _gemm(np.ones((32, 17)), np.ones((17, 32)), np.zeros((32, 32)), 1.0, 0.0, 0, tile=20)

@@ -2,6 +2,7 @@
 // (declared in include/glmmr_mcml_c.h under "test hooks").
 #include "dgemm_mfma.h"
 #include "dgemm_dl.h"
+#include "dgemm_band.h"
 
 using namespace mcml;
 
@@ -73,6 +74,63 @@ extern "C" int glmmr_mcml_dbg_dgemm_bench(int M, int N, int K, int b_nmajor, int
     float ms = 0;
     MCML_HIP(hipEventElapsedTime(&ms, e0, e1));
     *ms_per_launch = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return MCML_OK;
+}
+
+// Sustained shader clock under the banded FP64 MFMA kernel: a lower-triangular M x M operand
+// times an M x N matrix, `iters` launches; workgroup 0 accumulates s_memtime (shader clock) and
+// s_memrealtime (constant 100 MHz) over its lifetime.  out3 = [ms per launch, shader MHz, executed TFLOP/s]
+extern "C" int glmmr_mcml_dbg_band_clocks(int M, int N, int iters, int mode, double* out3)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device: libglmmr_mcml_hip has no CPU fallback");
+        return MCML_ENODEVICE;
+    }
+    hipStream_t s = nullptr;
+    std::vector<double> hA((size_t)M * M, 0.0), hB((size_t)M * N);
+    uint64_t x = 88172645463325252ULL;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (double)(x >> 11) / 9007199254740992.0 * 2 - 1; };
+    for (int j = 0; j < M; ++j) for (int i = j; i < M; ++i) hA[i + (size_t)j * M] = rnd();
+    for (auto& v : hB) v = rnd();
+    DevMat dA, dB, dC;
+    MCML_TRY(dA.alloc(M, M, 32));
+    MCML_HIP(hipMemset(dA.d(), 0, sizeof(double) * (size_t)dA.ld * dA.cols_alloc));
+    MCML_HIP(hipMemcpy2D(dA.d(), sizeof(double) * dA.ld, hA.data(), sizeof(double) * M, sizeof(double) * M, M, hipMemcpyHostToDevice));
+    MCML_TRY(dB.alloc(round_up(M, 32), N));
+    MCML_HIP(hipMemset(dB.d(), 0, sizeof(double) * (size_t)dB.ld * N));
+    MCML_HIP(hipMemcpy2D(dB.d(), sizeof(double) * dB.ld, hB.data(), sizeof(double) * M, sizeof(double) * M, N, hipMemcpyHostToDevice));
+    MCML_TRY(dC.alloc(M, N));
+    const int nbands = (M + BD_BM - 1) / BD_BM;
+    DevBuf kr, clk;
+    MCML_TRY(kr.ensure(sizeof(int) * 2 * nbands));
+    MCML_TRY(clk.ensure(16));
+    MCML_HIP(hipMemset(clk.p, 0, 16));
+    hipLaunchKernelGGL(k_band_ranges, dim3(nbands), dim3(256), 0, s, dA.d(), dA.ld, M, M, kr.as<int>());
+    std::vector<int> hk(2 * nbands);
+    MCML_HIP(hipMemcpy(hk.data(), kr.p, sizeof(int) * 2 * nbands, hipMemcpyDeviceToHost));
+    double tiles = 0;
+    for (int b = 0; b < nbands; ++b) tiles += hk[2 * b + 1] - hk[2 * b];
+    EpiAxpby epi{dC.d(), dC.ld, 1.0, 0.0};
+    for (int i = 0; i < 3; i++)
+        MCML_TRY(launch_gemm_band(s, M, N, M, dA.d(), dA.ld, dB.d(), dB.ld, kr.as<int>(), epi));
+    hipEvent_t e0, e1;
+    MCML_HIP(hipEventCreate(&e0));
+    MCML_HIP(hipEventCreate(&e1));
+    MCML_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; i++)
+        MCML_TRY(launch_gemm_band(s, M, N, M, dA.d(), dA.ld, dB.d(), dB.ld, kr.as<int>(), epi, clk.as<unsigned long long>(), mode));
+    MCML_HIP(hipEventRecord(e1, s));
+    MCML_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    MCML_HIP(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long hc[2] = {0, 0};
+    MCML_HIP(hipMemcpy(hc, clk.p, 16, hipMemcpyDeviceToHost));
+    out3[0] = ms / iters;
+    out3[1] = hc[1] ? (double)hc[0] / (double)hc[1] * 100.0 : 0.0;
+    out3[2] = 2.0 * 80.0 * 32.0 * tiles * N / (ms / iters * 1e-3) / 1e12;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return MCML_OK;

@@ -34,6 +34,8 @@ struct BandP {
     GemmP g;
     const int* krange;     // [2*band] first K tile, [2*band+1] one past the last (units of BD_BK)
     int nbands;
+    int mode;              // debug timing experiments: 1 no LDS-DMA, 2 no barriers, 4 no ds_reads (results meaningless)
+    unsigned long long* clocks;   // debug (nullable): workgroup 0 adds its shader-clock and 100 MHz real-time ticks
 };
 
 // first / last nonzero K tile of every 80-row band of A (M x K, column-major)
@@ -64,6 +66,46 @@ static __global__ __launch_bounds__(256) void k_band_ranges(const double* A, int
     }
 }
 
+// ---- hand-scheduled operand reads -------------------------------------------------------
+// The compiler's waitcnt insertion puts `s_waitcnt lgkmcnt(0)` in front of every MFMA group,
+// which also waits for the reads just issued for the NEXT group: measured (debug modes of
+// glmmr_mcml_dbg_band_clocks) the matrix pipe then idles ~14% of the K loop on LDS latency.
+// The reads are therefore issued through inline asm the compiler does not track, and the
+// counted waits are placed by hand (LDS returns in order: lgkmcnt(6) = "everything but the six
+// reads just issued").  The waits carry the operand registers as in/out operands so the MFMAs
+// that consume them cannot be scheduled above the wait.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BD_RD(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#else
+#define BD_RD(dst, addr, off) (dst = 0.0)
+#endif
+// operands of K substep KS (4 k's) of the stage whose per-lane byte addresses are aaddr / baddr
+template <int KS>
+__device__ __forceinline__ void bd_read(double (&a)[5], double& b, unsigned aaddr, unsigned baddr)
+{
+    BD_RD(a[0], aaddr, KS * 4 * BD_BM * 8);
+    BD_RD(a[1], aaddr, KS * 4 * BD_BM * 8 + 128);
+    BD_RD(a[2], aaddr, KS * 4 * BD_BM * 8 + 256);
+    BD_RD(a[3], aaddr, KS * 4 * BD_BM * 8 + 384);
+    BD_RD(a[4], aaddr, KS * 4 * BD_BM * 8 + 512);
+    BD_RD(b, baddr, KS * 2 * BD_BN * 16);
+}
+template <int LEAVE>
+__device__ __forceinline__ void bd_wait(double (&a)[5], double& b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (LEAVE == 6)
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b));
+#endif
+}
+__device__ __forceinline__ void bd_mfma(d4 (&acc)[5][1], const double (&a)[5], double b)
+{
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a[i], acc[i][0], 0, 0, 0);
+}
+
 template <class Epi>
 __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
 {
@@ -72,6 +114,8 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
     char* lds = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lk = lane >> 4;
+    unsigned long long t0c = 0, t0r = 0;
+    if (bp.clocks && blockIdx.x == 0 && tid == 0) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
 
     // XCD-aware map over (band pair, column tile)
     const int npairs = (bp.nbands + 1) >> 1;
@@ -146,7 +190,46 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
         for (int i = 0; i < 5; ++i) acc[i][0] = d4{0.0, 0.0, 0.0, 0.0};
 
         const int nk = kt1 - kt0;
-        if (nk > 0) {
+        const int mode = bp.mode;
+        if (nk > 0 && mode == 0) {
+            // per-lane LDS byte addresses of the operand reads inside stage 0
+            const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)lds;
+            const unsigned aoff = lds0 + lk * (BD_BM * 8) + l15 * 8;
+            const unsigned boff = lds0 + BD_A_BYTES + (((lk >> 1) * BD_BN + wave * 16 + l15) << 4) + ((lk & 1) << 3);
+            int issued = 0;
+            for (; issued < BD_STAGES - 1 && issued < nk; ++issued) issue(issued);
+            wait_leave(issued - 1);
+            __builtin_amdgcn_s_barrier();
+            int st = 0;
+            double ra[2][5], rb[2];
+            bd_read<0>(ra[0], rb[0], aoff, boff);
+            for (int kt = 0; kt < nk; ++kt) {
+                if (issued < nk) {
+                    int sn = st + BD_STAGES - 1; if (sn >= BD_STAGES) sn -= BD_STAGES;
+                    issue(sn);
+                    ++issued;
+                }
+                const unsigned aaddr = aoff + st * BD_STAGE_BYTES, baddr = boff + st * BD_STAGE_BYTES;
+                int stn = st + 1; if (stn >= BD_STAGES) stn = 0;
+#define BD_STEP(KS, CUR, NXT)                                   \
+                bd_read<KS + 1>(ra[NXT], rb[NXT], aaddr, baddr); \
+                bd_wait<6>(ra[CUR], rb[CUR]);                    \
+                bd_mfma(acc, ra[CUR], rb[CUR]);                  \
+                __builtin_amdgcn_sched_barrier(0);
+                BD_STEP(0, 0, 1) BD_STEP(1, 1, 0) BD_STEP(2, 0, 1) BD_STEP(3, 1, 0)
+                BD_STEP(4, 0, 1) BD_STEP(5, 1, 0) BD_STEP(6, 0, 1)
+#undef BD_STEP
+                // last substep: synchronise first (this wave's pieces of tile kt+1 landed, its own
+                // reads of tile kt complete), start the next tile's first reads, then the MFMAs
+                wait_leave(issued - kt - 2);
+                bd_wait<0>(ra[1], rb[1]);
+                __builtin_amdgcn_s_barrier();
+                if (kt + 1 < nk) bd_read<0>(ra[0], rb[0], aoff + stn * BD_STAGE_BYTES, boff + stn * BD_STAGE_BYTES);
+                bd_mfma(acc, ra[1], rb[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                st = stn;
+            }
+        } else if (nk > 0 && mode == 8) {
             int issued = 0;
             for (; issued < BD_STAGES - 1 && issued < nk; ++issued) issue(issued);
             wait_leave(issued - 1);
@@ -175,18 +258,59 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
                 __builtin_amdgcn_s_barrier();
                 st = st + 1; if (st >= BD_STAGES) st = 0;
             }
+        } else if (nk > 0) {
+            // timing experiments (debug hook only): the same loop with parts switched off
+            int issued = 0;
+            if (!(mode & 1)) {
+                for (; issued < BD_STAGES - 1 && issued < nk; ++issued) issue(issued);
+                wait_leave(issued - 1);
+            }
+            __builtin_amdgcn_s_barrier();
+            int st = 0;
+            double a[5] = {1.0 + lane, 2.0, 3.0, 4.0, 5.0}, b = 0.5 + lane;
+            for (int kt = 0; kt < nk; ++kt) {
+                if (!(mode & 1) && issued < nk) {
+                    int sn = st + BD_STAGES - 1; if (sn >= BD_STAGES) sn -= BD_STAGES;
+                    issue(sn);
+                    ++issued;
+                }
+                const double* as = reinterpret_cast<const double*>(lds + st * BD_STAGE_BYTES);
+                const double* bs = reinterpret_cast<const double*>(lds + st * BD_STAGE_BYTES + BD_A_BYTES);
+#pragma unroll
+                for (int ks = 0; ks < BD_BK / 4; ++ks) {
+                    const int kk = 4 * ks + lk;
+                    if (!(mode & 4)) {
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) a[i] = as[kk * BD_BM + 16 * i + l15];
+                        b = bs[((kk >> 1) * BD_BN + wave * 16 + l15) * 2 + (kk & 1)];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+                        acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a[i], acc[i][0], 0, 0, 0);
+                }
+                if (!(mode & 1)) wait_leave(issued - kt - 2);
+                if (!(mode & 2)) __builtin_amdgcn_s_barrier();
+                st = st + 1; if (st >= BD_STAGES) st = 0;
+            }
         }
         epi(acc, m0, n0 + wave * 16, lane, p.M, p.N, band);
         // the next band's first LDS-DMA may overwrite a stage another wave is still reading
         __builtin_amdgcn_s_barrier();
     }
+    if (bp.clocks && blockIdx.x == 0 && tid == 0) {
+        atomicAdd(bp.clocks, __builtin_amdgcn_s_memtime() - t0c);
+        atomicAdd(bp.clocks + 1, __builtin_amdgcn_s_memrealtime() - t0r);
+    }
 }
 
 template <class Epi>
 static inline int launch_gemm_band(hipStream_t s, int M, int N, int K, const double* A, int lda,
-                                   const double* B, int ldb, const int* krange, const Epi& epi)
+                                   const double* B, int ldb, const int* krange, const Epi& epi,
+                                   unsigned long long* clocks = nullptr, int mode = 0)
 {
     BandP bp;
+    bp.clocks = clocks;
+    bp.mode = mode;
     bp.g = GemmP{M, N, K, A, lda, B, ldb, 0, (N + BD_BN - 1) / BD_BN, 0, 0};
     bp.krange = krange;
     bp.nbands = (M + BD_BM - 1) / BD_BM;

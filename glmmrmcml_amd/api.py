@@ -243,6 +243,33 @@ class Context:
         return dict(beta=b, theta=t, sigma=sg.value, converged=bool(conv.value), iters=it.value,
                     accept_rate=d.accept_rate, mean_e=d.mean_e, leapfrog_total=d.leapfrog_total)
 
+    def mcml_la(self, start, usehess=False, tol=1e-3, verbose=False, trace=0, maxiter=10, nr=False, maxfun=0):
+        """mcml_la / mcml_la_nr on the resident model (src/mcml_la.cpp:28-290)"""
+        start = _f(start).ravel(); R = self.npar()
+        b = np.zeros(self.P); t = np.zeros(R); sg = C.c_double(); conv = C.c_int(); it = C.c_int()
+        se = np.zeros(start.size); u = np.zeros(self.Q)
+        e = self._ext(0, 1, maxfun)
+        _lib.check(_lib.lib().glmmr_mcml_ctx_la(
+            self._h, _p(start), start.size, int(nr), int(usehess), C.c_double(tol), int(verbose), int(trace),
+            int(maxiter), C.byref(e), _p(b), _p(t), C.byref(sg), _p(se), _p(u), C.byref(conv), C.byref(it)))
+        return dict(beta=b, theta=t, sigma=sg.value, se=se, u=u, converged=bool(conv.value), iters=it.value)
+
+    def la_probe(self, start, kind, v=None, var_par=1.0, par=None):
+        """test hook: LA functor values (kind 0, 1, 2) or one mcnr_b step (kind 3)"""
+        start = _f(start).ravel()
+        vv = None if v is None else _f(v).ravel()
+        if kind == 3:
+            vo = np.zeros(self.Q); bo = np.zeros(self.P); so = C.c_double()
+            _lib.check(_lib.lib().glmmr_mcml_dbg_la_probe(self._h, _p(start), start.size, 3, _p(vv),
+                                                          C.c_double(var_par), None, 0, None, _p(vo), _p(bo),
+                                                          C.byref(so)))
+            return dict(v=vo, beta=bo, sigma=so.value)
+        pr = _f(par).ravel(); out = C.c_double()
+        _lib.check(_lib.lib().glmmr_mcml_dbg_la_probe(self._h, _p(start), start.size, int(kind), _p(vv),
+                                                      C.c_double(var_par), _p(pr), pr.size, C.byref(out), None, None,
+                                                      None))
+        return out.value
+
     def profile(self, enable=True, reset=False):
         out = np.zeros(8)
         _lib.check(_lib.lib().glmmr_mcml_ctx_profile(self._h, int(enable), int(reset), _p(out)))
@@ -283,6 +310,31 @@ def mcml_full(cov, data, eff_range, Z, X, y, family, link, start, mcnr=False, m=
                                  int(maxsteps), C.c_double(target_accept), C.byref(e), _p(b), _p(t), C.byref(sg),
                                  C.byref(conv), _p(u), p.Q, C.byref(uc)))
     return dict(beta=b, theta=t, sigma=sg.value, converged=bool(conv.value), u=u[:, :uc.value])
+
+
+def _la_call(fn, cov, data, eff_range, Z, X, y, family, link, start, usehess, tol, verbose, trace, maxiter, maxfun):
+    p, keep = _problem(cov, data, eff_range, Z, X, y, family, link)
+    start = _f(start).ravel()
+    R = int(start.size - p.P - 1)
+    b = np.zeros(p.P); t = np.zeros(R); sg = C.c_double(); se = np.zeros(start.size); u = np.zeros(p.Q)
+    e = Ext(0, 1, int(maxfun), 0)
+    _lib.check(fn(C.byref(p), _p(start), start.size, int(usehess), C.c_double(tol), int(verbose), int(trace),
+                  int(maxiter), C.byref(e), _p(b), _p(t), C.byref(sg), _p(se), _p(u)))
+    return dict(beta=b, theta=t, sigma=sg.value, se=se, u=u.reshape(-1, 1))
+
+
+def mcml_la(cov, data, eff_range, Z, X, y, family, link, start, usehess=False, tol=1e-3, verbose=True, trace=0,
+            maxiter=10, maxfun=0):
+    """mcml_la(...) -> dict(beta, theta, sigma, se, u)   (src/mcml_la.cpp:28-155)"""
+    return _la_call(_lib.lib().glmmr_mcml_la, cov, data, eff_range, Z, X, y, family, link, start, usehess, tol,
+                    verbose, trace, maxiter, maxfun)
+
+
+def mcml_la_nr(cov, data, eff_range, Z, X, y, family, link, start, usehess=False, tol=1e-3, verbose=True, trace=0,
+               maxiter=10, maxfun=0):
+    """mcml_la_nr(...) -> dict(beta, theta, sigma, se, u)   (src/mcml_la.cpp:174-290)"""
+    return _la_call(_lib.lib().glmmr_mcml_la_nr, cov, data, eff_range, Z, X, y, family, link, start, usehess, tol,
+                    verbose, trace, maxiter, maxfun)
 
 
 def mcmc_sample(Z, L, X, y, beta, family, link, warmup, nsamp, lambda_, var_par=1, trace=0, refresh=500,

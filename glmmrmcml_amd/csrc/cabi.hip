@@ -289,6 +289,11 @@ int drv_full(Ctx& c, const double* start, int nstart, int mcnr, int m, int maxit
              int verbose, double lambda, int trace, int refresh, int maxsteps, double target_accept,
              const glmmr_mcml_ext* e, double* beta_out, double* theta_out, double* sigma_out,
              int* converged_out, int* iters_out, glmmr_mcml_hmc_diag* last_diag);
+int drv_la(Ctx& c, const double* start, int nstart, int nr, int usehess, double tol, int verbose, int trace,
+           int maxiter, const glmmr_mcml_ext* e, double* beta, double* theta, double* sigma, double* se, double* u,
+           int* converged, int* iters);
+int drv_la_probe(Ctx& c, const double* start, int nstart, int kind, const double* v, double var_par,
+                 const double* par, int npar, double* out, double* v_out, double* beta_out, double* sigma_out);
 }
 
 extern "C" int glmmr_mcml_sample_cols(int m, int chains)
@@ -372,6 +377,28 @@ extern "C" int glmmr_mcml_ctx_full(glmmr_mcml_ctx* h, const double* start, int n
     MCML_HIP(hipSetDevice(h->c.device));
     return drv_full(h->c, start, nstart, mcnr, m, maxiter, warmup, tol, verbose, lambda, trace, refresh, maxsteps,
                     target_accept, ext, beta, theta, sigma, converged, iters, diag);
+}
+
+// Laplace-approximation fits (src/mcml_la.cpp): nr = 0 mcml_la, 1 mcml_la_nr
+extern "C" int glmmr_mcml_ctx_la(glmmr_mcml_ctx* h, const double* start, int nstart, int nr, int usehess, double tol,
+                                 int verbose, int trace, int maxiter, const glmmr_mcml_ext* ext, double* beta,
+                                 double* theta, double* sigma, double* se, double* u, int* converged, int* iters)
+{
+    MCML_REQUIRE(h && start && beta && theta && sigma, "mcml_la: null argument");
+    MCML_HIP(hipSetDevice(h->c.device));
+    return drv_la(h->c, start, nstart, nr, usehess, tol, verbose, trace, maxiter, ext, beta, theta, sigma, se, u,
+                  converged, iters);
+}
+
+extern "C" int glmmr_mcml_dbg_la_probe(glmmr_mcml_ctx* h, const double* start, int nstart, int kind, const double* v,
+                                       double var_par, const double* par, int npar, double* out, double* v_out,
+                                       double* beta_out, double* sigma_out)
+{
+    MCML_REQUIRE(h && start, "la_probe: null argument");
+    MCML_REQUIRE(kind >= 0 && kind <= 3, "la_probe: kind %d", kind);
+    MCML_REQUIRE(kind == 3 ? (v_out && beta_out && sigma_out) : (par && out && npar > 0), "la_probe: null output");
+    MCML_HIP(hipSetDevice(h->c.device));
+    return drv_la_probe(h->c, start, nstart, kind, v, var_par, par, npar, out, v_out, beta_out, sigma_out);
 }
 
 // ---- host-buffer mirrors of the Rcpp exports ----
@@ -536,6 +563,26 @@ extern "C" int glmmr_mcml_full(const glmmr_mcml_problem* prob, const double* sta
     if (ucols) *ucols = g.h->c.mcols;
     if (u) MCML_TRY(glmmr_mcml_get_u(g.h, u, ldu));
     return MCML_OK;
+}
+
+extern "C" int glmmr_mcml_la(const glmmr_mcml_problem* prob, const double* start, int nstart, int usehess, double tol,
+                             int verbose, int trace, int maxiter, const glmmr_mcml_ext* ext, double* beta,
+                             double* theta, double* sigma, double* se, double* u)
+{
+    CtxGuard g;
+    MCML_TRY(open_ctx(prob, ext, g));
+    return glmmr_mcml_ctx_la(g.h, start, nstart, 0, usehess, tol, verbose, trace, maxiter, ext, beta, theta, sigma, se,
+                             u, nullptr, nullptr);
+}
+
+extern "C" int glmmr_mcml_la_nr(const glmmr_mcml_problem* prob, const double* start, int nstart, int usehess,
+                                double tol, int verbose, int trace, int maxiter, const glmmr_mcml_ext* ext,
+                                double* beta, double* theta, double* sigma, double* se, double* u)
+{
+    CtxGuard g;
+    MCML_TRY(open_ctx(prob, ext, g));
+    return glmmr_mcml_ctx_la(g.h, start, nstart, 1, usehess, tol, verbose, trace, maxiter, ext, beta, theta, sigma, se,
+                             u, nullptr, nullptr);
 }
 
 extern "C" int glmmr_mcml_mcmc_sample(const double* Z, const double* L, const double* X, const double* y, int n,

@@ -77,6 +77,7 @@ struct Ctx {
     DevBuf z_idx, z_val;        // n x z_width (column-major)
     std::vector<int> h_zidx; std::vector<double> h_zval;   // host copy of the same
     SparseZL sp;
+    bool no_sparse_zl = false;  // the Laplace path works on the dense ZL / ZLT
     CovSpec cov;
     DevMat Z, X;                // n x Q, n x P
     DevBuf y;                   // n
@@ -137,6 +138,9 @@ int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out);
 // L = genD(0, chol=true, upper=false) (mcml_full.cpp:68): block-diagonal lower factor
 int mvn_gen_L(Ctx& c, const double* theta, bool chol);
 int potrf_lower(Ctx& c, double* A, int n, int lda);                          // in place
+int potrf_lower_checked(Ctx& c, double* A, int n, int lda);                  // + MCML_ENOTPD if a pivot failed
+// x <- (L L')^-1 x for one vector, L from the LAST potrf_lower (its diagonal-block inverses are in c.linv)
+int potrs_lower_vec(Ctx& c, const double* L, int ldl, int n, double* x, double* tmp);
 int trsm_left_lower(Ctx& c, const double* L, int ldl, int n, double* U, int ldu, int m);
 
 // ---- model.hip ----

@@ -218,7 +218,7 @@ int model_update_L(Ctx& c)
 {
     MCML_REQUIRE(c.n > 0 && c.have_L, "update_L: no model / L");
     if (!c.sp.built) MCML_TRY(sparse_zl_setup(c));
-    if (c.sp.possible && c.L.ld == pad_ld(c.Q)) {
+    if (c.sp.possible && !c.no_sparse_zl && c.L.ld == pad_ld(c.Q)) {
         const long tot = (long)c.n * c.sp.W;
         hipLaunchKernelGGL(k_ell_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c.stream,
                            c.sp.ell_src.as<int>(), c.sp.ell_z.d(), c.L.d(), tot, c.sp.ell_val.d());

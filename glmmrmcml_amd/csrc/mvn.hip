@@ -681,6 +681,12 @@ static int check_errflag(Ctx& c, const char* what)
     return MCML_OK;
 }
 
+int potrf_lower_checked(Ctx& c, double* A, int n, int lda)
+{
+    MCML_TRY(potrf_lower(c, A, n, lda));
+    return check_errflag(c, "potrf");
+}
+
 // ------------------------------------------------------------------ loglik
 int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out)
 {

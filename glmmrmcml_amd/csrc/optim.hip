@@ -126,13 +126,17 @@ public:
         // covariance parameters (lower bound 1e-6, mcmloptim.h:35-38) that means evaluating the
         // MVN likelihood at a variance of 1e-12: an objective ~1e11 that wrecks the first models.
         // When no rhobeg was asked for, keep an interior start interior instead: the default is
-        // also capped by half the distance to the nearest bound.
+        // also capped by half the distance to the nearest bound.  A coordinate that sits within
+        // 1e-3 of the nominal radius of a bound (e.g. a variance an earlier fit drove onto 1e-6, give
+        // or take round-off) IS on that bound: it is snapped there instead of shrinking the radius
+        // to nothing.
         if (!(o_.rhobeg > 0)) {
+            const double near = 1e-3 * rhobeg;
             for (int i = 0; i < n; ++i) {
-                const double xi = std::min(std::max(x0_[i], lo_[i]), up_[i]);
+                double xi = std::min(std::max(x0_[i], lo_[i]), up_[i]);
                 const double dl = xi - lo_[i], du = up_[i] - xi;
-                if (std::isfinite(dl) && dl > 0) rhobeg = std::min(rhobeg, 0.5 * dl);
-                if (std::isfinite(du) && du > 0) rhobeg = std::min(rhobeg, 0.5 * du);
+                if (std::isfinite(dl) && dl > 0) { if (dl < near) x0_[i] = lo_[i]; else rhobeg = std::min(rhobeg, 0.5 * dl); }
+                if (std::isfinite(du) && du > 0) { if (du < near) x0_[i] = up_[i]; else rhobeg = std::min(rhobeg, 0.5 * du); }
             }
         }
         const double rhoend = o_.rhoend > 0 ? std::min(o_.rhoend, rhobeg) : 1e-6 * rhobeg;

@@ -214,12 +214,35 @@ int glmmr_mcml_hess_sparse(const glmmr_mcml_problem* prob, const int32_t* Ap, co
 int glmmr_mcml_aic(const glmmr_mcml_problem* prob, const double* u, int ucols, const double* beta_par,
                    int nbeta, const double* cov_par, int ncov, const glmmr_mcml_ext* ext, double* out);
 
+/* mcml_la / mcml_la_nr(cov, data, eff_range, Z, X, y, family, link, start, usehess, tol, verbose, trace,
+ * maxiter) -> List(beta, theta, sigma, se, u)   -- src/mcml_la.cpp:28-155 / 174-290
+ * Laplace-approximation fits: (beta, v) by BOBYQA (mcml_la) or one Newton-Raphson step per iteration
+ * (mcml_la_nr), theta (+ sigma) by BOBYQA on ll - v'v/2 - logdet(ZL' W ZL + I)/2, then a joint polish.
+ * se: nstart entries (zeros unless usehess); u: Q entries (= L v).  ext->maxfun bounds each BOBYQA run. */
+int glmmr_mcml_la(const glmmr_mcml_problem* prob, const double* start, int nstart, int usehess, double tol,
+                  int verbose, int trace, int maxiter, const glmmr_mcml_ext* ext, double* beta, double* theta,
+                  double* sigma, double* se, double* u);
+int glmmr_mcml_la_nr(const glmmr_mcml_problem* prob, const double* start, int nstart, int usehess, double tol,
+                     int verbose, int trace, int maxiter, const glmmr_mcml_ext* ext, double* beta, double* theta,
+                     double* sigma, double* se, double* u);
+/* the same on a resident context (nr = 0 / 1); converged / iters nullable */
+int glmmr_mcml_ctx_la(glmmr_mcml_ctx* ctx, const double* start, int nstart, int nr, int usehess, double tol,
+                      int verbose, int trace, int maxiter, const glmmr_mcml_ext* ext, double* beta, double* theta,
+                      double* sigma, double* se, double* u, int* converged, int* iters);
+
 /* mvn_ll(cov, data, eff_range, gamma, u)  -- src/mcml_optim.cpp:406-414 */
 int glmmr_mcml_mvn_ll(const int32_t* cov, int cov_rows, const double* data, int data_len,
                       const double* eff_range, int eff_len, const double* gamma, int ngamma,
                       const double* u, int Q, int m, double* out);
 
 /* ---- test hooks (building blocks exposed for tests/ and bench.py only) ---- */
+/* Laplace path pieces from the state the drivers start in (model built from `start`, v given, W as
+ * update_W leaves it): kind 0 LA_likelihood(par = beta, v), 1 LA_likelihood_cov(par = theta[, var_par]),
+ * 2 LA_likelihood_btheta(par = beta, theta[, var_par]) -> *out (likelihood.h:112-230);
+ * kind 3 one mcnr_b step (mcmloptim.h:238-293) -> v_out (Q), beta_out (P), sigma_out */
+int glmmr_mcml_dbg_la_probe(glmmr_mcml_ctx* ctx, const double* start, int nstart, int kind, const double* v,
+                            double var_par, const double* par, int npar, double* out, double* v_out,
+                            double* beta_out, double* sigma_out);
 int glmmr_mcml_dbg_dgemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb,
                          int b_nmajor, double alpha, double beta, double* C, int ldc,
                          int lower_only, int force_tile /* -1 = auto */);

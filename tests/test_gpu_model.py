@@ -1,0 +1,68 @@
+"""ModelMCML (the caller, glmmrmcml_amd/model.py) end to end on the real exports (GPU): the fit it assembles equals
+the direct export call with the same seed, the stepwise / sparse loop lands on the same estimates as the dense
+one, and MCML and LA agree on an easy model."""
+import numpy as np
+import pytest
+
+from glmmrmcml_amd import api, synth
+from glmmrmcml_amd.model import ModelMCML
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(family="poisson"):
+    d = synth.cluster_rct(ncl=8, nt=3, nind=8, seed=5, family=family)
+    m = ModelMCML(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["family"], d["link"], d["beta"], d["theta"],
+                  x_names=["int"] + ["t%d" % i for i in range(1, d["P"])], cov_names=["gr(cl)", "gr(cl,t)"])
+    m.mcmc_options.update(warmup=60, samps=64, lambda_=0.5, maxsteps=10)
+    return d, m
+
+
+def test_mcml_equals_direct_export_and_fills_the_record():
+    d, m = _setup()
+    fit = m.MCML(d["y"], verbose=False, max_iter=4, seed=99, chains=8, options=dict(maxfun=60))
+    direct = api.mcml_full(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"],
+                           np.r_[d["beta"], d["theta"], 1.0], mcnr=True, m=64, maxiter=4, warmup=60, tol=1e-2,
+                           verbose=False, lambda_=0.5, maxsteps=10, target_accept=0.95, seed=99, chains=8, maxfun=60)
+    P = d["P"]
+    assert np.array_equal(fit["theta"][:P], direct["beta"]) and np.array_equal(fit["theta"][P:P + 2], direct["theta"])
+    co = fit["coefficients"]
+    assert co["par"][:P + 2] == ["int", "t1", "t2", "t3", "gr(cl)", "gr(cl,t)"][:P + 2]
+    assert np.all(co["SE"][:P] > 0) and np.all(np.isnan(co["SE"][P:P + 2]))
+    assert fit["re_samps"].shape == (d["Q"], 64) and np.isfinite(fit["aic"])
+    assert 0 < fit["Rsq"]["marg"] <= fit["Rsq"]["cond"] < 1
+    assert len(fit.table()) == P + 2 and "cAIC" in str(fit)
+
+
+def test_hessian_se_and_simlik_step():
+    d, m = _setup()
+    fit = m.MCML(d["y"], verbose=False, max_iter=3, seed=7, chains=8, se_method="lik", sim_lik_step=True,
+                 options=dict(maxfun=80))
+    P = d["P"]
+    se = fit["coefficients"]["SE"][:P + 2]
+    assert np.all(np.isfinite(se[:P])) and np.all(se[:P] > 0)
+    assert fit["sim_lik"] is True
+
+
+def test_stepwise_dense_and_sparse_agree():
+    d, m = _setup()
+    a = m.MCML(d["y"], verbose=False, sampler="stepwise", max_iter=3, seed=11, chains=8, options=dict(maxfun=80))
+    b = m.MCML(d["y"], verbose=False, sampler="stepwise", sparse=True, max_iter=3, seed=11, chains=8,
+               options=dict(maxfun=80))
+    P = d["P"]
+    # same seeds -> same samples in iteration 1; later iterations differ only through L (previous theta vs LDL')
+    assert np.allclose(a["theta"][:P], b["theta"][:P], atol=0.1)
+    assert np.all(b["theta"][P:P + 2] >= 1e-6)
+
+
+def test_la_through_the_caller():
+    d, m = _setup()
+    f = m.LA(d["y"], method="nr")
+    g = m.LA(d["y"], method="nr", use_hess=True)
+    P = d["P"]
+    assert np.allclose(f["theta"], g["theta"])
+    assert np.all(f["coefficients"]["SE"][:P] > 0) and np.all(g["coefficients"]["SE"][:P + 2] > 0)
+    assert f["re_samps"].shape == (d["Q"], 1)
+    # sanity only: the Laplace and the (short, 8-cluster) MCML fits of this model land in the same place
+    h = m.MCML(d["y"], verbose=False, max_iter=5, seed=3, chains=16, options=dict(maxfun=60))
+    assert np.allclose(f["theta"][:P], h["theta"][:P], atol=0.35)

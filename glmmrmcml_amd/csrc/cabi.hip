@@ -390,6 +390,12 @@ extern "C" int glmmr_mcml_ctx_la(glmmr_mcml_ctx* h, const double* start, int nst
                   converged, iters);
 }
 
+extern "C" int glmmr_mcml_dbg_leaf_profile(glmmr_mcml_ctx* h, unsigned long long* out10)
+{
+    MCML_REQUIRE(h && out10, "leaf_profile: null argument");
+    return potrf_leaf_profile(h->c, out10);
+}
+
 extern "C" int glmmr_mcml_dbg_la_probe(glmmr_mcml_ctx* h, const double* start, int nstart, int kind, const double* v,
                                        double var_par, const double* par, int npar, double* out, double* v_out,
                                        double* beta_out, double* sigma_out)

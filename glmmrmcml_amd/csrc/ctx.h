@@ -138,6 +138,7 @@ int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out);
 // L = genD(0, chol=true, upper=false) (mcml_full.cpp:68): block-diagonal lower factor
 int mvn_gen_L(Ctx& c, const double* theta, bool chol);
 int potrf_lower(Ctx& c, double* A, int n, int lda);                          // in place
+int potrf_leaf_profile(Ctx& c, unsigned long long* host10);                 // debug: phase clocks of one leaf
 int potrf_lower_checked(Ctx& c, double* A, int n, int lda);                  // + MCML_ENOTPD if a pivot failed
 // x <- (L L')^-1 x for one vector, L from the LAST potrf_lower (its diagonal-block inverses are in c.linv)
 int potrs_lower_vec(Ctx& c, const double* L, int ldl, int n, double* x, double* tmp);

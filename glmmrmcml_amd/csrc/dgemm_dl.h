@@ -216,8 +216,10 @@ static inline int launch_gemm_dl_cfg(hipStream_t s, GemmP p, const Epi& epi)
     return MCML_OK;
 }
 
-// tile: 0 = pick, 1 = 128 x 128 (needed when C aliases B with M <= 128, or A with N <= 128),
-// 2 = 64 x 128 (twice the workgroups for small trailing matrices; in-place only for C aliasing A)
+// tile: 0 = pick, 1 = 128 x 128 (C may alias B with M <= 128, or A with N <= 128),
+// 2 = 64 x 128 (twice the workgroups for small trailing matrices; in-place only for C aliasing A),
+// 3 = 128 x 32 (the 128 x m diagonal-block products of the blocked TRSM: m / 32 workgroups instead of
+//     m / 128; C may alias B with M <= 128)
 template <bool BNMAJOR, class Epi>
 static inline int launch_gemm_dl(hipStream_t s, int M, int N, int K, const double* A, int lda,
                                  const double* B, int ldb, const Epi& epi, bool lower_only = false, int tile = 0)
@@ -231,6 +233,7 @@ static inline int launch_gemm_dl(hipStream_t s, int M, int N, int K, const doubl
         tile = t128 >= 192 ? 1 : 2;
     }
     if (tile == 1) return launch_gemm_dl_cfg<4, 2, 2, 4, BNMAJOR, 4, Epi>(s, p, epi);
+    if (tile == 3) return launch_gemm_dl_cfg<1, 2, 8, 1, BNMAJOR, 6, Epi>(s, p, epi);
     return launch_gemm_dl_cfg<2, 2, 2, 4, BNMAJOR, 5, Epi>(s, p, epi);
 }
 

@@ -179,19 +179,37 @@ __device__ __forceinline__ double bcast_lane(double v)
 template <int C, int J>
 __device__ __forceinline__ void potrf16_upd(double (&a)[16], double l, int r)
 {
+    // rows r < J hold (never read) upper-triangle entries: updating them too saves the select
     const double lj = bcast_lane<J>(l);
-    if (r >= J) a[J] -= l * lj;
+    a[J] = __builtin_fma(-l, lj, a[J]);
     if constexpr (J < 15) potrf16_upd<C, J + 1>(a, l, r);
 }
 
+// 1 / sqrt(x) to double precision without the division: v_rsq_f64 seed (~2^-26) + two Newton
+// steps, all fused multiply-adds (about 8 dependent instructions instead of ~35 for sqrt + div:
+// the 16 x 16 diagonal tile is a serial chain, one of these per column)
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    double e = __builtin_fma(-(h * y), y, 0.5);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-(h * y), y, 0.5);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+
 template <int C>
-__device__ __forceinline__ void potrf16_col(double (&a)[16], int r, int lane, int* errflag)
+__device__ __forceinline__ void potrf16_col(double (&a)[16], int r, int lane, int* errflag, double* rdiag)
 {
     double diag = bcast_lane<C>(a[C]);
     if (!(diag > 0.0)) { if (lane == 0) atomicExch(errflag, 1); diag = 1.0; }
-    const double d = sqrt(diag);
-    const double l = (r == C) ? d : a[C] / d;
+    const double y = rsqrt_nr(diag);
+    double d = diag * y;                                   // sqrt(diag), one correction step
+    d = __builtin_fma(__builtin_fma(-d, d, diag), 0.5 * y, d);
+    const double l = (r == C) ? d : a[C] * y;
     a[C] = l;
+    if (lane == 0) rdiag[C] = y;                           // 1 / L_cc: the panel solve and the inverse reuse it
     if constexpr (C < 15) {
         // a[j] -= l * l_j for j > C, l_j = lane j's l
         potrf16_upd<C, C + 1>(a, l, r);
@@ -203,8 +221,12 @@ __device__ __forceinline__ void potrf16_col(double (&a)[16], int r, int lane, in
 // 16-wide panels (the 16x16 diagonal tile in registers via wave shuffles), then
 // inverts the factor in place into the unused upper triangle.  Writes L over
 // the lower triangle of A and inv(L) to Linv (128 x 128, ld 128, upper zeroed).
-__global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, double* Linv, int* errflag)
+__global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, double* Linv, int* errflag,
+                                                    unsigned long long* prof)
 {
+#pragma clang fp contract(fast)      // the factorisation is not part of the bit-exact RNG / leapfrog contract
+#define LEAF_T(i) do { if (prof && threadIdx.x == 0) prof[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    LEAF_T(0);
     extern __shared__ __attribute__((aligned(16))) double S[];
     constexpr int LS = 129;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -222,24 +244,28 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, d
         }
     }
     __syncthreads();
+    LEAF_T(1);
+    unsigned long long ta = 0, tb = 0, tc = 0, t_;
     const int ntile = (n + 15) >> 4;
     for (int kt = 0; kt < ntile; ++kt) {
         const int kb = kt * 16;
+        t_ = __builtin_amdgcn_s_memtime();
         if (wave == 0) {
             // (a) 16x16 diagonal tile, one row per lane (lanes >= 16 mirror lane&15)
             const int r = lane & 15;
+            double* rdiag = S + 128 * LS + kb;             // reciprocal diagonal = the inverse's diagonal (xd)
             double a[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c)
                 a[c] = (kb + r < n && kb + c < n) ? S[(kb + r) * LS + kb + c] : (r == c ? 1.0 : 0.0);
-            potrf16_col<0>(a, r, lane, errflag);  potrf16_col<1>(a, r, lane, errflag);
-            potrf16_col<2>(a, r, lane, errflag);  potrf16_col<3>(a, r, lane, errflag);
-            potrf16_col<4>(a, r, lane, errflag);  potrf16_col<5>(a, r, lane, errflag);
-            potrf16_col<6>(a, r, lane, errflag);  potrf16_col<7>(a, r, lane, errflag);
-            potrf16_col<8>(a, r, lane, errflag);  potrf16_col<9>(a, r, lane, errflag);
-            potrf16_col<10>(a, r, lane, errflag); potrf16_col<11>(a, r, lane, errflag);
-            potrf16_col<12>(a, r, lane, errflag); potrf16_col<13>(a, r, lane, errflag);
-            potrf16_col<14>(a, r, lane, errflag); potrf16_col<15>(a, r, lane, errflag);
+            potrf16_col<0>(a, r, lane, errflag, rdiag);  potrf16_col<1>(a, r, lane, errflag, rdiag);
+            potrf16_col<2>(a, r, lane, errflag, rdiag);  potrf16_col<3>(a, r, lane, errflag, rdiag);
+            potrf16_col<4>(a, r, lane, errflag, rdiag);  potrf16_col<5>(a, r, lane, errflag, rdiag);
+            potrf16_col<6>(a, r, lane, errflag, rdiag);  potrf16_col<7>(a, r, lane, errflag, rdiag);
+            potrf16_col<8>(a, r, lane, errflag, rdiag);  potrf16_col<9>(a, r, lane, errflag, rdiag);
+            potrf16_col<10>(a, r, lane, errflag, rdiag); potrf16_col<11>(a, r, lane, errflag, rdiag);
+            potrf16_col<12>(a, r, lane, errflag, rdiag); potrf16_col<13>(a, r, lane, errflag, rdiag);
+            potrf16_col<14>(a, r, lane, errflag, rdiag); potrf16_col<15>(a, r, lane, errflag, rdiag);
             if (lane < 16) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
@@ -247,6 +273,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, d
             }
         }
         __syncthreads();
+        ta += __builtin_amdgcn_s_memtime() - t_; t_ = __builtin_amdgcn_s_memtime();
         // (b) panel below the tile: x L11^T = a, one row per thread (rows padded to the tile grid
         // are zero and stay zero)
         for (int i = kb + 16 + tid; i < ntile * 16; i += 256) {
@@ -256,13 +283,13 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, d
                 double s = S[i * LS + kb + c];
 #pragma unroll
                 for (int k = 0; k < c; ++k) s -= x[k] * S[(kb + c) * LS + kb + k];
-                const double dg = S[(kb + c) * LS + kb + c];
-                x[c] = (kb + c < n) ? s / dg : 0.0;
+                x[c] = (kb + c < n) ? s * S[128 * LS + kb + c] : 0.0;
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c) S[i * LS + kb + c] = x[c];
         }
         __syncthreads();
+        tb += __builtin_amdgcn_s_memtime() - t_; t_ = __builtin_amdgcn_s_memtime();
         // (c) trailing update of the lower tiles on the matrix cores: C -= P P^T, K = 16
         const int t0 = kt + 1, nrem = ntile - t0;
         const int ntri = nrem * (nrem + 1) / 2;
@@ -284,7 +311,10 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, d
             for (int r = 0; r < 4; ++r) S[(ri + (lane >> 4) + 4 * r) * LS + rj + (lane & 15)] = acc[r];
         }
         __syncthreads();
+        tc += __builtin_amdgcn_s_memtime() - t_;
     }
+    if (prof && threadIdx.x == 0) { prof[2] = ta; prof[3] = tb; prof[4] = tc; }
+    LEAF_T(5);
     {   // write L
         const int i = tid & 127, j0 = tid >> 7;
         if (i < n)
@@ -292,6 +322,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, d
     }
     // ---- inverse X = inv(L), 16 x 16 tiles; X[i][j] (i > j) is kept at S[j][i] (the unused
     // upper triangle), its diagonal in xd ----
+    LEAF_T(6);
     double* xd = S + 128 * LS;            // 128 doubles
     double* Tt = xd + 128;                // 7 tiles of 16 x 16
     const int nt = (n + 15) >> 4;
@@ -303,23 +334,23 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, d
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 double v = 0.0;
-                if (r == c) v = 1.0 / S[(base + r) * LS + base + r];
+                if (r == c) v = xd[base + r];
                 else if (r > c && base + r < n) {
                     double sacc = 0.0;
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
                         if (k >= c && k < r) sacc += S[(base + r) * LS + base + k] * x[k];
-                    v = -sacc / S[(base + r) * LS + base + r];
+                    v = -sacc * xd[base + r];
                 }
                 x[r] = v;
             }
-            xd[base + c] = x[c];
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (r > c && base + r < n) S[(base + c) * LS + base + r] = x[r];
         }
     }
     __syncthreads();
+    LEAF_T(7);
     // (2) block rows: X_IJ = -X_II * sum_{K=J}^{I-1} L_IK X_KJ, the 16x16x16 tile products on
     // the matrix cores (one (I, J) tile per wave at a time)
     for (int I = 1; I < nt; ++I) {
@@ -363,6 +394,7 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, d
         }
         __syncthreads();
     }
+    LEAF_T(8);
     for (int e = tid; e < 128 * 128; e += 256) {
         int i = e & 127, j = e >> 7;
         double v = 0.0;
@@ -372,6 +404,30 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, d
         }
         Linv[i + j * 128] = v;
     }
+    LEAF_T(9);
+#undef LEAF_T
+}
+
+// debug: phase timestamps (shader clock) of one 128 x 128 leaf on a random SPD block
+int potrf_leaf_profile(Ctx& c, unsigned long long* host10)
+{
+    DevMat A; DevBuf prof;
+    MCML_TRY(A.alloc(128, 128));
+    MCML_TRY(prof.ensure(80));
+    MCML_TRY(c.linv.ensure(sizeof(double) * 2 * CHOL_NB * CHOL_NB));
+    std::vector<double> h((size_t)A.ld * 128, 0.0);
+    for (int j = 0; j < 128; ++j) for (int i = 0; i < 128; ++i) h[i + (size_t)j * A.ld] = (i == j ? 130.0 : 1.0 / (1 + abs(i - j)));
+    MCML_HIP(hipMemcpy(A.d(), h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    MCML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_leaf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(sizeof(double) * (128 * 129 + 128 + 7 * 256))));
+    for (int rep = 0; rep < 3; ++rep) {
+        MCML_HIP(hipMemcpy(A.d(), h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), sizeof(double) * (128 * 129 + 128 + 7 * 256), c.stream, A.d(), A.ld,
+                           128, c.linv.d(), c.scalars.as<int>() + 32, prof.as<unsigned long long>());
+        MCML_HIP(hipStreamSynchronize(c.stream));
+    }
+    MCML_HIP(hipMemcpy(host10, prof.p, 80, hipMemcpyDeviceToHost));
+    return MCML_OK;
 }
 
 __global__ void k_copy_block(double* dst, int ldd, const double* src, int lds, int rows, int cols)
@@ -455,7 +511,7 @@ static int potrf_rec(Ctx& c, double* A0, int lda, int off, int n)
     if (n <= CHOL_NB) {
         double* Linv = c.linv.d() + (size_t)(off / CHOL_NB) * CHOL_NB * CHOL_NB;
         hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), POTRF_LDS, c.stream,
-                           A, lda, n, Linv, c.scalars.as<int>() + 32);
+                           A, lda, n, Linv, c.scalars.as<int>() + 32, nullptr);
         MCML_HIP(hipGetLastError());
         return MCML_OK;
     }
@@ -479,7 +535,8 @@ static int chol_gemm(hipStream_t s, int M, int N, int K, const double* A, int ld
 {
     static const bool use_dl = !(getenv("GLMMR_MCML_CHOL_GEMM") && !strcmp(getenv("GLMMR_MCML_CHOL_GEMM"), "reg"));
     if (use_dl && dl_applicable(M, N, K, A, lda, B, ldb, BNMAJOR))
-        return launch_gemm_dl<BNMAJOR>(s, M, N, K, A, lda, B, ldb, epi, lower_only, inplace == 2 ? 1 : 0);
+        return launch_gemm_dl<BNMAJOR>(s, M, N, K, A, lda, B, ldb, epi, lower_only,
+                                       inplace == 2 ? (N >= 256 ? 3 : 1) : 0);
     return launch_gemm<BNMAJOR>(s, M, N, K, A, lda, B, ldb, epi, lower_only, inplace ? inplace : -1);
 }
 
@@ -523,7 +580,7 @@ static int potrf_blocked(Ctx& c, double* A, int lda, int n)
     int* errflag = c.scalars.as<int>() + 32;
     auto leaf = [&](hipStream_t s, int k, int nb) -> int {
         hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), POTRF_LDS, s, A + k + (size_t)k * lda, lda, nb,
-                           c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB, errflag);
+                           c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB, errflag, nullptr);
         MCML_HIP(hipGetLastError());
         return MCML_OK;
     };

@@ -236,6 +236,9 @@ int glmmr_mcml_mvn_ll(const int32_t* cov, int cov_rows, const double* data, int 
                       const double* u, int Q, int m, double* out);
 
 /* ---- test hooks (building blocks exposed for tests/ and bench.py only) ---- */
+/* shader-clock timestamps of the phases of one 128 x 128 Cholesky leaf: [start, loaded, sum (a) diagonal tiles,
+ * sum (b) panel solves, sum (c) trailing updates, factor done, L written, inverse diag done, inverse done, end] */
+int glmmr_mcml_dbg_leaf_profile(glmmr_mcml_ctx* ctx, unsigned long long* out10);
 /* Laplace path pieces from the state the drivers start in (model built from `start`, v given, W as
  * update_W leaves it): kind 0 LA_likelihood(par = beta, v), 1 LA_likelihood_cov(par = theta[, var_par]),
  * 2 LA_likelihood_btheta(par = beta, theta[, var_par]) -> *out (likelihood.h:112-230);

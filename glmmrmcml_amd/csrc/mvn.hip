@@ -199,17 +199,22 @@ __device__ __forceinline__ double rsqrt_nr(double x)
     return y;
 }
 
+// One column of the 16 x 16 diagonal tile, branch-free (the 16 columns are one serial dependency
+// chain on a single wave: every exec-mask branch in it costs a pipeline bubble).  `bad`
+// accumulates failed pivots, `yv` collects lane r's reciprocal pivot 1 / L_rr.
 template <int C>
-__device__ __forceinline__ void potrf16_col(double (&a)[16], int r, int lane, int* errflag, double* rdiag)
+__device__ __forceinline__ void potrf16_col(double (&a)[16], int r, int& bad, double& yv)
 {
     double diag = bcast_lane<C>(a[C]);
-    if (!(diag > 0.0)) { if (lane == 0) atomicExch(errflag, 1); diag = 1.0; }
+    const bool ok = diag > 0.0;
+    bad |= ok ? 0 : 1;
+    diag = ok ? diag : 1.0;
     const double y = rsqrt_nr(diag);
     double d = diag * y;                                   // sqrt(diag), one correction step
     d = __builtin_fma(__builtin_fma(-d, d, diag), 0.5 * y, d);
     const double l = (r == C) ? d : a[C] * y;
+    yv = (r == C) ? y : yv;
     a[C] = l;
-    if (lane == 0) rdiag[C] = y;                           // 1 / L_cc: the panel solve and the inverse reuse it
     if constexpr (C < 15) {
         // a[j] -= l * l_j for j > C, l_j = lane j's l
         potrf16_upd<C, C + 1>(a, l, r);
@@ -221,7 +226,8 @@ __device__ __forceinline__ void potrf16_col(double (&a)[16], int r, int lane, in
 // 16-wide panels (the 16x16 diagonal tile in registers via wave shuffles), then
 // inverts the factor in place into the unused upper triangle.  Writes L over
 // the lower triangle of A and inv(L) to Linv (128 x 128, ld 128, upper zeroed).
-__global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, double* Linv, int* errflag,
+constexpr int LEAF_NT = 512, LEAF_NW = LEAF_NT / 64;      // 8 waves: the panel / trailing / inverse phases are wave-parallel
+__global__ __launch_bounds__(LEAF_NT) void k_potrf_leaf(double* A, int lda, int n, double* Linv, int* errflag,
                                                     unsigned long long* prof)
 {
 #pragma clang fp contract(fast)      // the factorisation is not part of the bit-exact RNG / leapfrog contract
@@ -231,69 +237,132 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, d
     constexpr int LS = 129;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {   // load the lower triangle: thread = (row, column parity); 16 loads in flight per thread
+        constexpr int JG = LEAF_NT / 128;
         const int i = tid & 127, j0 = tid >> 7;
-        for (int jb = 0; jb < 128; jb += 32) {
+        for (int jb = 0; jb < 128; jb += 16 * JG) {
             double v[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int j = jb + j0 + 2 * q;
+                const int j = jb + j0 + JG * q;
                 v[q] = (i < n && j < n && i >= j) ? A[i + (size_t)j * lda] : 0.0;
             }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) S[i * LS + jb + j0 + 2 * q] = v[q];
+            for (int q = 0; q < 16; ++q) S[i * LS + jb + j0 + JG * q] = v[q];
         }
     }
     __syncthreads();
     LEAF_T(1);
     unsigned long long ta = 0, tb = 0, tc = 0, t_;
     const int ntile = (n + 15) >> 4;
+    // ---- inverse X = inv(L), 16 x 16 tiles; X[i][j] (i > j) is kept at S[j][i] (the unused upper
+    // triangle), its diagonal (= the reciprocal pivots phase (a) stores) in xd.  Block row I is
+    // complete once tile (I, I) is factorised, so waves 1..7 compute row I of the inverse while
+    // wave 0 runs the serial phase (a) of step I + 1: off the critical path.  Wave w owns column
+    // tile J = w - 1 and keeps its T_J in a private scratch tile -- no barrier is needed inside
+    // the row.  The diagonal tiles X_II cost nothing: phase (b) solves x L11' = e_j for the 16
+    // rows of the identity along with the panel rows, which is X_II' written straight into the
+    // upper part of the diagonal tile.
+    double* xd = S + 128 * LS;            // 128 doubles
+    double* Tt = xd + 128;                // 7 tiles of 16 x 16
+    auto inverse_row = [&](int I) {
+        const int J = wave - 1;
+        const int l15 = lane & 15, lk = lane >> 4;
+        if (J >= I) return;
+        // T_J = sum_{K=J}^{I-1} L_IK X_KJ on the matrix cores
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int K = J; K < I; ++K) {
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const int t = kc * 4 + lk;
+                // A operand: L_IK[row l15][t];  B operand: X_KJ[t][col l15]
+                const double pa = S[(I * 16 + l15) * LS + K * 16 + t];
+                double pb;
+                if (K == J) pb = (t == l15) ? xd[J * 16 + l15] : (t > l15 ? S[(J * 16 + l15) * LS + J * 16 + t] : 0.0);
+                else pb = S[(J * 16 + l15) * LS + K * 16 + t];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
+            }
+        }
+        // T_J[row][col]: row = lk + 4 r, col = l15 -> this wave's scratch tile
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tt[J * 256 + (lk + 4 * r) * 16 + l15] = acc[r];
+        // X_IJ = -X_II T_J
+        d4 acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const int t = kc * 4 + lk;
+            // A operand: X_II[row l15][t] (lower triangular);  B operand: T_J[t][col l15]
+            const double pa = (t == l15) ? xd[I * 16 + l15]
+                                         : (t < l15 ? S[(I * 16 + t) * LS + I * 16 + l15] : 0.0);
+            const double pb = Tt[J * 256 + t * 16 + l15];
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gi = I * 16 + lk + 4 * r, gj = J * 16 + l15;
+            if (gi < n) S[gj * LS + gi] = -acc2[r];
+        }
+    };
     for (int kt = 0; kt < ntile; ++kt) {
         const int kb = kt * 16;
         t_ = __builtin_amdgcn_s_memtime();
         if (wave == 0) {
             // (a) 16x16 diagonal tile, one row per lane (lanes >= 16 mirror lane&15)
             const int r = lane & 15;
-            double* rdiag = S + 128 * LS + kb;             // reciprocal diagonal = the inverse's diagonal (xd)
+            int bad = 0; double yv = 1.0;                  // failed pivots; this lane's reciprocal pivot
             double a[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c)
                 a[c] = (kb + r < n && kb + c < n) ? S[(kb + r) * LS + kb + c] : (r == c ? 1.0 : 0.0);
-            potrf16_col<0>(a, r, lane, errflag, rdiag);  potrf16_col<1>(a, r, lane, errflag, rdiag);
-            potrf16_col<2>(a, r, lane, errflag, rdiag);  potrf16_col<3>(a, r, lane, errflag, rdiag);
-            potrf16_col<4>(a, r, lane, errflag, rdiag);  potrf16_col<5>(a, r, lane, errflag, rdiag);
-            potrf16_col<6>(a, r, lane, errflag, rdiag);  potrf16_col<7>(a, r, lane, errflag, rdiag);
-            potrf16_col<8>(a, r, lane, errflag, rdiag);  potrf16_col<9>(a, r, lane, errflag, rdiag);
-            potrf16_col<10>(a, r, lane, errflag, rdiag); potrf16_col<11>(a, r, lane, errflag, rdiag);
-            potrf16_col<12>(a, r, lane, errflag, rdiag); potrf16_col<13>(a, r, lane, errflag, rdiag);
-            potrf16_col<14>(a, r, lane, errflag, rdiag); potrf16_col<15>(a, r, lane, errflag, rdiag);
+            potrf16_col<0>(a, r, bad, yv);  potrf16_col<1>(a, r, bad, yv);
+            potrf16_col<2>(a, r, bad, yv);  potrf16_col<3>(a, r, bad, yv);
+            potrf16_col<4>(a, r, bad, yv);  potrf16_col<5>(a, r, bad, yv);
+            potrf16_col<6>(a, r, bad, yv);  potrf16_col<7>(a, r, bad, yv);
+            potrf16_col<8>(a, r, bad, yv);  potrf16_col<9>(a, r, bad, yv);
+            potrf16_col<10>(a, r, bad, yv); potrf16_col<11>(a, r, bad, yv);
+            potrf16_col<12>(a, r, bad, yv); potrf16_col<13>(a, r, bad, yv);
+            potrf16_col<14>(a, r, bad, yv); potrf16_col<15>(a, r, bad, yv);
             if (lane < 16) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
                     if (r >= c && kb + r < n && kb + c < n) S[(kb + r) * LS + kb + c] = a[c];
+                S[128 * LS + kb + r] = yv;                 // reciprocal diagonal = the inverse's diagonal (xd)
+                if (bad && lane == 0) atomicExch(errflag, 1);
             }
+        } else if (kt >= 1) {
+            inverse_row(kt - 1);
         }
         __syncthreads();
         ta += __builtin_amdgcn_s_memtime() - t_; t_ = __builtin_amdgcn_s_memtime();
         // (b) panel below the tile: x L11^T = a, one row per thread (rows padded to the tile grid
-        // are zero and stay zero)
-        for (int i = kb + 16 + tid; i < ntile * 16; i += 256) {
-            double x[16];
+        // are zero and stay zero).  The tile's own 16 rows ride along with right-hand side e_j:
+        // their solution is row j of inv(L11)', i.e. X_II, stored in the tile's upper part.
+        // Right-looking substitution: once x[k] is known every later column's partial sum is updated
+        // at once, so the 120 multiply-adds of a row pipeline instead of forming 16 long chains.
+        {
+            const bool ident = wave == LEAF_NW - 1;        // the last wave: lanes 0-15 = the identity rows
+            const int jj = lane;
+            const int i = ident ? kb + jj : kb + 16 + tid;
+            if (ident ? (lane < 16) : (i < ntile * 16)) {
+                double sv[16], x[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                double s = S[i * LS + kb + c];
+                for (int c = 0; c < 16; ++c) sv[c] = ident ? (c == jj ? 1.0 : 0.0) : S[i * LS + kb + c];
 #pragma unroll
-                for (int k = 0; k < c; ++k) s -= x[k] * S[(kb + c) * LS + kb + k];
-                x[c] = (kb + c < n) ? s * S[128 * LS + kb + c] : 0.0;
+                for (int k = 0; k < 16; ++k) {
+                    x[k] = (kb + k < n) ? sv[k] * S[128 * LS + kb + k] : 0.0;
+#pragma unroll
+                    for (int c = k + 1; c < 16; ++c) sv[c] -= x[k] * S[(kb + c) * LS + kb + k];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (!ident || c > jj) S[i * LS + kb + c] = x[c];
             }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) S[i * LS + kb + c] = x[c];
         }
         __syncthreads();
         tb += __builtin_amdgcn_s_memtime() - t_; t_ = __builtin_amdgcn_s_memtime();
         // (c) trailing update of the lower tiles on the matrix cores: C -= P P^T, K = 16
         const int t0 = kt + 1, nrem = ntile - t0;
         const int ntri = nrem * (nrem + 1) / 2;
-        for (int t = wave; t < ntri; t += 4) {
+        for (int t = wave; t < ntri; t += LEAF_NW) {
             int ti = 0, rem = t;                       // t -> (ti >= tj) in row-major triangle order
             while (rem > ti) { rem -= ti + 1; ++ti; }
             const int tj = rem;
@@ -318,84 +387,15 @@ __global__ __launch_bounds__(256) void k_potrf_leaf(double* A, int lda, int n, d
     {   // write L
         const int i = tid & 127, j0 = tid >> 7;
         if (i < n)
-            for (int j = j0; j <= i && j < n; j += 2) A[i + (size_t)j * lda] = S[i * LS + j];
+            for (int j = j0; j <= i && j < n; j += LEAF_NT / 128) A[i + (size_t)j * lda] = S[i * LS + j];
     }
-    // ---- inverse X = inv(L), 16 x 16 tiles; X[i][j] (i > j) is kept at S[j][i] (the unused
-    // upper triangle), its diagonal in xd ----
+    // the last block row of the inverse (the earlier ones were done under the later steps' phase (a))
     LEAF_T(6);
-    double* xd = S + 128 * LS;            // 128 doubles
-    double* Tt = xd + 128;                // 7 tiles of 16 x 16
-    const int nt = (n + 15) >> 4;
-    // (1) diagonal tiles: one thread per column, forward substitution in registers
-    if (tid < 128) {
-        const int I = tid >> 4, c = tid & 15, base = I * 16;
-        if (base + c < n) {
-            double x[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                double v = 0.0;
-                if (r == c) v = xd[base + r];
-                else if (r > c && base + r < n) {
-                    double sacc = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        if (k >= c && k < r) sacc += S[(base + r) * LS + base + k] * x[k];
-                    v = -sacc * xd[base + r];
-                }
-                x[r] = v;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (r > c && base + r < n) S[(base + c) * LS + base + r] = x[r];
-        }
-    }
+    if (wave >= 1) inverse_row(ntile - 1);
     __syncthreads();
     LEAF_T(7);
-    // (2) block rows: X_IJ = -X_II * sum_{K=J}^{I-1} L_IK X_KJ, the 16x16x16 tile products on
-    // the matrix cores (one (I, J) tile per wave at a time)
-    for (int I = 1; I < nt; ++I) {
-        for (int J = wave; J < I; J += 4) {
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-            const int l15 = lane & 15, lk = lane >> 4;
-            for (int K = J; K < I; ++K) {
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc) {
-                    const int t = kc * 4 + lk;
-                    // A operand: L_IK[row l15][t];  B operand: X_KJ[t][col l15]
-                    const double pa = S[(I * 16 + l15) * LS + K * 16 + t];
-                    double pb;
-                    if (K == J) pb = (t == l15) ? xd[J * 16 + l15] : (t > l15 ? S[(J * 16 + l15) * LS + J * 16 + t] : 0.0);
-                    else pb = S[(J * 16 + l15) * LS + K * 16 + t];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
-                }
-            }
-            // T_J[row][col]: row = lk + 4 r, col = l15
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Tt[J * 256 + (lk + 4 * r) * 16 + l15] = acc[r];
-        }
-        __syncthreads();
-        for (int J = wave; J < I; J += 4) {   // X_IJ = -X_II T_J
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-            const int l15 = lane & 15, lk = lane >> 4;
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                const int t = kc * 4 + lk;
-                // A operand: X_II[row l15][t] (lower triangular);  B operand: T_J[t][col l15]
-                const double pa = (t == l15) ? xd[I * 16 + l15]
-                                             : (t < l15 ? S[(I * 16 + t) * LS + I * 16 + l15] : 0.0);
-                const double pb = Tt[J * 256 + t * 16 + l15];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = I * 16 + lk + 4 * r, gj = J * 16 + l15;
-                if (gi < n) S[gj * LS + gi] = -acc[r];
-            }
-        }
-        __syncthreads();
-    }
     LEAF_T(8);
-    for (int e = tid; e < 128 * 128; e += 256) {
+    for (int e = tid; e < 128 * 128; e += LEAF_NT) {
         int i = e & 127, j = e >> 7;
         double v = 0.0;
         if (i < n && j < n) {
@@ -422,7 +422,7 @@ int potrf_leaf_profile(Ctx& c, unsigned long long* host10)
                                  (int)(sizeof(double) * (128 * 129 + 128 + 7 * 256))));
     for (int rep = 0; rep < 3; ++rep) {
         MCML_HIP(hipMemcpy(A.d(), h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), sizeof(double) * (128 * 129 + 128 + 7 * 256), c.stream, A.d(), A.ld,
+        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(LEAF_NT), sizeof(double) * (128 * 129 + 128 + 7 * 256), c.stream, A.d(), A.ld,
                            128, c.linv.d(), c.scalars.as<int>() + 32, prof.as<unsigned long long>());
         MCML_HIP(hipStreamSynchronize(c.stream));
     }
@@ -510,7 +510,7 @@ static int potrf_rec(Ctx& c, double* A0, int lda, int off, int n)
     double* A = A0 + off + (size_t)off * lda;
     if (n <= CHOL_NB) {
         double* Linv = c.linv.d() + (size_t)(off / CHOL_NB) * CHOL_NB * CHOL_NB;
-        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), POTRF_LDS, c.stream,
+        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(LEAF_NT), POTRF_LDS, c.stream,
                            A, lda, n, Linv, c.scalars.as<int>() + 32, nullptr);
         MCML_HIP(hipGetLastError());
         return MCML_OK;
@@ -579,7 +579,7 @@ static int potrf_blocked(Ctx& c, double* A, int lda, int n)
     if (la_any) MCML_TRY(lookahead_setup(c));
     int* errflag = c.scalars.as<int>() + 32;
     auto leaf = [&](hipStream_t s, int k, int nb) -> int {
-        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), POTRF_LDS, s, A + k + (size_t)k * lda, lda, nb,
+        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(LEAF_NT), POTRF_LDS, s, A + k + (size_t)k * lda, lda, nb,
                            c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB, errflag, nullptr);
         MCML_HIP(hipGetLastError());
         return MCML_OK;

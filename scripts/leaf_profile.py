@@ -15,6 +15,5 @@ print("(b) panel solve", t[3])
 print("(c) trailing   ", t[4])
 print("factor total   ", t[5] - t[1])
 print("write L        ", t[6] - t[5])
-print("inverse diag   ", t[7] - t[6])
-print("inverse rows   ", t[8] - t[7])
+print("last inverse row", t[7] - t[6], " (rows 0..6 run under phase (a) of the following step)")
 print("write Linv     ", t[9] - t[8])

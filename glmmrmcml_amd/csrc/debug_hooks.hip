@@ -79,6 +79,47 @@ extern "C" int glmmr_mcml_dbg_dgemm_bench(int M, int N, int K, int b_nmajor, int
     return MCML_OK;
 }
 
+// C = A * B through the banded kernel (dgemm_band.h) exactly as the sampler uses it: A is copied into a
+// buffer whose columns are zero-padded to a multiple of 32, B's rows likewise, the K-tile ranges come from
+// k_band_ranges.  For tests/ only.
+extern "C" int glmmr_mcml_dbg_dgemm_band(int M, int N, int K, const double* A, int lda, const double* B, int ldb,
+                                         double* C, int ldc, int* tiles_executed)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device: libglmmr_mcml_hip has no CPU fallback");
+        return MCML_ENODEVICE;
+    }
+    MCML_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "dbg_dgemm_band: bad argument");
+    hipStream_t s = nullptr;
+    DevMat dA, dB, dC;
+    MCML_TRY(dA.alloc(M, K, 32));
+    MCML_HIP(hipMemset(dA.d(), 0, sizeof(double) * (size_t)dA.ld * dA.cols_alloc));
+    MCML_HIP(hipMemcpy2D(dA.d(), sizeof(double) * dA.ld, A, sizeof(double) * lda, sizeof(double) * M, K, hipMemcpyHostToDevice));
+    MCML_TRY(dB.alloc(round_up(K, 32), N));
+    MCML_HIP(hipMemset(dB.d(), 0, sizeof(double) * (size_t)dB.ld * N));
+    MCML_HIP(hipMemcpy2D(dB.d(), sizeof(double) * dB.ld, B, sizeof(double) * ldb, sizeof(double) * K, N, hipMemcpyHostToDevice));
+    MCML_TRY(dC.alloc(M, N));
+    MCML_HIP(hipMemset(dC.d(), 0, sizeof(double) * (size_t)dC.ld * N));
+    MCML_REQUIRE(dlds_applicable(M, N, K, dA.d(), dA.ld, dA.cols_alloc, dB.d(), dB.ld), "dbg_dgemm_band: contract");
+    const int nbands = (M + BD_BM - 1) / BD_BM;
+    DevBuf kr;
+    MCML_TRY(kr.ensure(sizeof(int) * 2 * nbands));
+    hipLaunchKernelGGL(k_band_ranges, dim3(nbands), dim3(256), 0, s, dA.d(), dA.ld, M, K, kr.as<int>());
+    MCML_HIP(hipGetLastError());
+    if (tiles_executed) {
+        std::vector<int> hk(2 * nbands);
+        MCML_HIP(hipMemcpy(hk.data(), kr.p, sizeof(int) * 2 * nbands, hipMemcpyDeviceToHost));
+        int t = 0;
+        for (int b = 0; b < nbands; ++b) t += hk[2 * b + 1] - hk[2 * b];
+        *tiles_executed = t;
+    }
+    EpiAxpby epi{dC.d(), dC.ld, 1.0, 0.0};
+    MCML_TRY(launch_gemm_band(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, kr.as<int>(), epi));
+    MCML_TRY(download_matrix(C, ldc, dC.d(), dC.ld, M, N, s));
+    return MCML_OK;
+}
+
 // Sustained shader clock under the banded FP64 MFMA kernel: a lower-triangular M x M operand
 // times an M x N matrix, `iters` launches; workgroup 0 accumulates s_memtime (shader clock) and
 // s_memrealtime (constant 100 MHz) over its lifetime.  out3 = [ms per launch, shader MHz, executed TFLOP/s]

@@ -264,6 +264,10 @@ int glmmr_mcml_dbg_fd_hessian(glmmr_mcml_objective f, void* user, int n, const d
                               int usebounds, const double* lower, const double* upper, double* H);
 int glmmr_mcml_dbg_dgemm_bench(int M, int N, int K, int b_nmajor, int iters, int force_tile,
                                double* ms_per_launch);
+/* C = A B through the banded zero-skipping kernel of the sampler (dgemm_band.h); tiles_executed (nullable) =
+ * K tiles of 32 actually multiplied, summed over the 80-row bands */
+int glmmr_mcml_dbg_dgemm_band(int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C,
+                              int ldc, int* tiles_executed);
 /* sustained shader clock under the banded FP64 MFMA kernel: out3 = [ms per launch, shader MHz, executed TFLOP/s] */
 int glmmr_mcml_dbg_band_clocks(int M, int N, int iters, int mode, double* out3);
 /* mode: 0 the real kernel; timing experiments (results meaningless): 1 no LDS-DMA, 2 no barriers, 4 no ds_reads */

@@ -88,3 +88,58 @@ def test_dgemm_dl_rejects_ragged_k():
     from glmmrmcml_amd import _lib
     with pytest.raises(_lib.McmlError):
         _gemm(np.ones((32, 17)), np.ones((17, 32)), np.zeros((32, 32)), 1.0, 0.0, 0, tile=20)
+
+
+# ---- the banded zero-skipping kernel of the HMC products (dgemm_band.h) ----
+def _band(A, B):
+    from glmmrmcml_amd import _lib
+    L = _lib.lib()
+    M, K = A.shape
+    N = B.shape[1]
+    A = np.asfortranarray(A); B = np.asfortranarray(B); out = np.zeros((M, N), order="F")
+    tiles = C.c_int()
+    _lib.check(L.glmmr_mcml_dbg_dgemm_band(M, N, K, A.ctypes.data_as(dp), M, B.ctypes.data_as(dp), K,
+                                           out.ctypes.data_as(dp), M, C.byref(tiles)))
+    return out, tiles.value
+
+
+def _check_band(A, B):
+    got, tiles = _band(A, B)
+    want = A @ B
+    bound = 1e-12 * (np.abs(A) @ np.abs(B)) + 1e-300
+    assert np.all(np.abs(got - want) <= bound)
+    return tiles
+
+
+@pytest.mark.parametrize("M,N,K", [(5000, 1024, 5000), (80, 128, 32), (81, 129, 33), (333, 77, 250), (1000, 1, 999),
+                                   (160, 300, 2000), (2000, 256, 2000)])
+def test_band_lower_triangular(M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    A = np.tril(rng.normal(size=(M, K)))
+    tiles = _check_band(A, rng.normal(size=(K, N)))
+    nb, kt = (M + 79) // 80, (K + 31) // 32
+    assert tiles <= nb * kt
+    if M == K and M >= 1000:
+        assert tiles < 0.6 * nb * kt                        # about half the K tiles are skipped
+
+
+@pytest.mark.parametrize("M,N,K", [(5000, 1024, 5000), (333, 77, 250), (81, 129, 33)])
+def test_band_upper_triangular_and_dense(M, N, K):
+    rng = np.random.default_rng(7 * M + N)
+    B = rng.normal(size=(K, N))
+    _check_band(np.triu(rng.normal(size=(M, K))), B)
+    tiles = _check_band(rng.normal(size=(M, K)), B)
+    assert tiles == ((M + 79) // 80) * ((K + 31) // 32)      # nothing to skip
+
+
+def test_band_general_band_and_empty_bands():
+    rng = np.random.default_rng(99)
+    M, K, N = 1300, 1700, 200
+    A = rng.normal(size=(M, K))
+    i, k = np.indices((M, K))
+    A[np.abs(k - (i * K) // M) > 150] = 0.0                  # a diagonal band of half-width 150
+    A[400:560, :] = 0.0                                      # two whole 80-row bands of zeros
+    tiles = _check_band(A, rng.normal(size=(K, N)))
+    assert tiles < 0.35 * ((M + 79) // 80) * ((K + 31) // 32)
+    got, _ = _band(A, rng.normal(size=(K, N)))
+    assert np.all(got[400:560, :] == 0.0)

@@ -574,7 +574,7 @@ static int lookahead_setup(Ctx& c)
 static int potrf_blocked(Ctx& c, double* A, int lda, int n)
 {
     // look-ahead pays while the rest of the trailing update is at least as long as a leaf
-    static const int la_min = getenv("GLMMR_MCML_LA_MIN") ? atoi(getenv("GLMMR_MCML_LA_MIN")) : 2048;
+    static const int la_min = getenv("GLMMR_MCML_LA_MIN") ? atoi(getenv("GLMMR_MCML_LA_MIN")) : 1536;
     const bool la_any = chol_mode() == 1 && n - 2 * CHOL_NB >= la_min;
     if (la_any) MCML_TRY(lookahead_setup(c));
     int* errflag = c.scalars.as<int>() + 32;

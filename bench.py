@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--n", type=int, default=CFG["n"], help="override n = Q (debug only; invalidates the metric)")
+    ap.add_argument("--n", "--nobs", dest="n", type=int, default=CFG["n"], help="override n = Q (debug only; invalidates the metric)")
     ap.add_argument("--chains", type=int, default=CFG["chains_per_gpu"])
     args = ap.parse_args()
 
@@ -106,12 +106,20 @@ def main():
                              % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
+    # GLMMR_MCML_DIST_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks
+    # share devices, gloo carries the all-reduce of the CUDA tensors); the real run is nccl = RCCL over xGMI
+    backend = os.environ.get("GLMMR_MCML_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     hook = None
     if world > 1:
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            tdist.init_process_group(backend=backend)
         hook = gdist.make_reduce_hook()
 
     cfg = dict(CFG); cfg["n"] = args.n; cfg["chains_per_gpu"] = args.chains

@@ -104,28 +104,50 @@ struct EpiBackward {
             R[off] = rr;
         }
     }
+    // All loads of a 16-column group are issued (from clamped, always valid addresses) before the first
+    // use, so the epilogue pays one memory round trip instead of one per element; only the stores
+    // are predicated.  Arithmetic order per element is elem()'s.
     template <int TM, int TN>
     __device__ __forceinline__ void operator()(d4 (&acc)[TM][TN], int mB, int nB, int lane, int M, int N,
                                                int) const {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
+            int stv[4]; double env[4]; bool act[4]; size_t cb[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = nB + 16 * j + (lane >> 4) + 4 * r;
-                if (n >= N) continue;
-                int st = 0; double en = 0.0;
-                if (mode == 1) { st = steps[n]; en = e[n]; if (s >= st) continue; }
+                bool a = n < N;
+                const int nn = a ? n : 0;
+                int st_ = 0; double en_ = 0.0;
+                if (mode == 1) { st_ = steps[nn]; en_ = e[nn]; a = a && s < st_; }
+                act[r] = a; stv[r] = st_; env[r] = en_; cb[r] = (size_t)nn * ld;
+            }
+            double xv[TM][4], rv[TM][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mB + 16 * i + (lane & 15);
+                const int mm = m < M ? m : 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    xv[i][r] = Xs[mm + cb[r]];
+                    rv[i][r] = mode == 1 ? R[mm + cb[r]] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (!act[r]) continue;
+                const int st = stv[r]; const double en = env[r];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int m = mB + 16 * i + (lane & 15);
                     if (m >= M) continue;
-                    const size_t off = m + (size_t)n * ld;
-                    const double x = Xs[off];
+                    const size_t off = m + cb[r];
+                    const double x = xv[i][r];
                     double g = -1.0 * x;
                     g = g + post * acc[i][j][r];
                     if (mode != 1 || s + 1 >= st) G[off] = g;
                     if (mode == 1) {
-                        double rr = R[off];
+                        double rr = rv[i][r];
                         rr = rr + (en / 2) * g;
                         if (s + 1 < st) {
                             rr = rr + (en / 2) * g;
@@ -135,6 +157,7 @@ struct EpiBackward {
                     }
                 }
             }
+        }
     }
 };
 

@@ -24,7 +24,7 @@ extern "C" int glmmr_mcml_dbg_dgemm(int M, int N, int K, const double* A, int ld
     MCML_TRY(upload_matrix(dC, C, M, N, ldc, s));
     EpiAxpby epi{dC.d(), dC.ld, alpha, beta};
     int rc;
-    if (force_tile >= 20)      // 20 / 21 / 22: the deep-ring direct-to-LDS kernel (dgemm_dl.h), 128x128 / 64x128 / 128x32 tiles
+    if (force_tile >= 20)      // 20..25: the deep-ring direct-to-LDS kernel (dgemm_dl.h), tiles 1..6
         rc = b_nmajor ? launch_gemm_dl<true>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, lower_only != 0, force_tile - 19)
                       : launch_gemm_dl<false>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, lower_only != 0, force_tile - 19);
     else

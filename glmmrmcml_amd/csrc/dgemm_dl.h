@@ -216,13 +216,17 @@ static inline int launch_gemm_dl_cfg(hipStream_t s, GemmP p, const Epi& epi)
     return MCML_OK;
 }
 
-// tile: 0 = pick, 1 = 128 x 128 (C may alias B with M <= 128, or A with N <= 128),
-// 2 = 64 x 128 (twice the workgroups for small trailing matrices; in-place only for C aliasing A),
-// 3 = 128 x 32 (the 128 x m diagonal-block products of the blocked TRSM: m / 32 workgroups instead of
-//     m / 128; C may alias B with M <= 128)
+// tile: 0 = pick;  1 = 128 x 128, 4-stage ring (one workgroup per CU);  2 = 64 x 128, 5 stages;
+// 3 = 128 x 32 (the 128 x m diagonal-block products of the blocked TRSM: m / 32 workgroups);
+// 4 = 128 x 128 with a 2-stage ring (64 KB) and 5 = 64 x 128 with 3 stages (72 KB): TWO workgroups per
+// CU, so one's prologue / epilogue overlaps the other's MFMA work and the tile count quantises over 512
+// slots -- measured best for every K = 128 update of the Q = 5000 factorisation;  6 = 64 x 64, 4 waves,
+// 48 KB (three per CU).
+// inplace: 0 none; 1 = C aliases A (needs BN >= N); 2 = C aliases B (needs BM >= M).
 template <bool BNMAJOR, class Epi>
 static inline int launch_gemm_dl(hipStream_t s, int M, int N, int K, const double* A, int lda,
-                                 const double* B, int ldb, const Epi& epi, bool lower_only = false, int tile = 0)
+                                 const double* B, int ldb, const Epi& epi, bool lower_only = false, int tile = 0,
+                                 int inplace = 0)
 {
     MCML_REQUIRE(dl_applicable(M, N, K, A, lda, B, ldb, BNMAJOR), "dgemm_dl: shape/alignment contract violated "
                  "(M %d N %d K %d lda %d ldb %d)", M, N, K, lda, ldb);
@@ -230,10 +234,21 @@ static inline int launch_gemm_dl(hipStream_t s, int M, int N, int K, const doubl
     if (tile == 0) {
         long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
         if (lower_only) t128 = t128 / 2 + (M + 127) / 128;
-        tile = t128 >= 192 ? 1 : 2;
+        static const int big = getenv("GLMMR_MCML_DL_BIG") ? atoi(getenv("GLMMR_MCML_DL_BIG")) : 4;
+        static const int small = getenv("GLMMR_MCML_DL_SMALL") ? atoi(getenv("GLMMR_MCML_DL_SMALL")) : 5;
+        static const int thr = getenv("GLMMR_MCML_DL_THR") ? atoi(getenv("GLMMR_MCML_DL_THR")) : 768;
+        static const int thr64 = getenv("GLMMR_MCML_DL_THR64") ? atoi(getenv("GLMMR_MCML_DL_THR64")) : 128;
+        tile = t128 >= thr ? big : small;
+        if (inplace == 0 && t128 < thr64) tile = 6;
+        if (inplace == 2) tile = N >= 256 ? 3 : 1;
     }
+    MCML_REQUIRE(!(inplace == 1 && tile == 6 && N > 64) && !(inplace == 2 && (tile == 2 || tile == 5 || tile == 6) && M > 64),
+                 "dgemm_dl: tile %d cannot run this product in place", tile);
     if (tile == 1) return launch_gemm_dl_cfg<4, 2, 2, 4, BNMAJOR, 4, Epi>(s, p, epi);
     if (tile == 3) return launch_gemm_dl_cfg<1, 2, 8, 1, BNMAJOR, 6, Epi>(s, p, epi);
+    if (tile == 4) return launch_gemm_dl_cfg<4, 2, 2, 4, BNMAJOR, 2, Epi>(s, p, epi);
+    if (tile == 5) return launch_gemm_dl_cfg<2, 2, 2, 4, BNMAJOR, 3, Epi>(s, p, epi);
+    if (tile == 6) return launch_gemm_dl_cfg<2, 2, 2, 2, BNMAJOR, 3, Epi>(s, p, epi);
     return launch_gemm_dl_cfg<2, 2, 2, 4, BNMAJOR, 5, Epi>(s, p, epi);
 }
 

@@ -535,8 +535,7 @@ static int chol_gemm(hipStream_t s, int M, int N, int K, const double* A, int ld
 {
     static const bool use_dl = !(getenv("GLMMR_MCML_CHOL_GEMM") && !strcmp(getenv("GLMMR_MCML_CHOL_GEMM"), "reg"));
     if (use_dl && dl_applicable(M, N, K, A, lda, B, ldb, BNMAJOR))
-        return launch_gemm_dl<BNMAJOR>(s, M, N, K, A, lda, B, ldb, epi, lower_only,
-                                       inplace == 2 ? (N >= 256 ? 3 : 1) : 0);
+        return launch_gemm_dl<BNMAJOR>(s, M, N, K, A, lda, B, ldb, epi, lower_only, 0, inplace);
     return launch_gemm<BNMAJOR>(s, M, N, K, A, lda, B, ldb, epi, lower_only, inplace ? inplace : -1);
 }
 

@@ -61,7 +61,7 @@ def test_dgemm_lower_only_leaves_upper_tiles():
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (4872, 128, 128), (1000, 1024, 128), (131, 77, 16),
                                    (5, 3, 32), (777, 300, 256), (64, 128, 128)])
 @pytest.mark.parametrize("b_nmajor", [0, 1])
-@pytest.mark.parametrize("tile", [20, 21, 22])
+@pytest.mark.parametrize("tile", [20, 21, 22, 23, 24, 25])
 def test_dgemm_dl_matches_numpy(M, N, K, b_nmajor, tile):
     rng = np.random.default_rng(M * 5 + N * 11 + K)
     A = rng.normal(size=(M, K)); Bm = rng.normal(size=(K, N)); C0 = rng.normal(size=(M, N))
@@ -72,7 +72,7 @@ def test_dgemm_dl_matches_numpy(M, N, K, b_nmajor, tile):
     assert np.all(np.abs(got - want) <= bound)
 
 
-@pytest.mark.parametrize("tile", [20, 21])
+@pytest.mark.parametrize("tile", [20, 21, 23, 24, 25])
 def test_dgemm_dl_lower_only(tile):
     rng = np.random.default_rng(5)
     n, k = 900, 128

@@ -19,6 +19,7 @@
 #include "dgemm_mfma.h"
 #include "dgemm_dlds.h"
 #include "dgemm_band.h"
+#include "dgemm_band2.h"
 #include "glm.h"
 #include "reduce.h"
 #include "rng.h"
@@ -384,6 +385,14 @@ static bool use_dlds()
     return v == 1;
 }
 
+// GLMMR_MCML_BAND=2: the two-workgroups-per-CU cut of the banded kernel (dgemm_band2.h)
+static int band_variant()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GLMMR_MCML_BAND"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 // MU = xb + ZL * X ; S = score
 static int hmc_forward(Ctx& c, const double* X, int ldx, bool store_mu = true)
 {
@@ -397,7 +406,9 @@ static int hmc_forward(Ctx& c, const double* X, int ldx, bool store_mu = true)
                            c.sp.W, c.sp.ell_col.as<int>(), c.sp.ell_val.d(), X, ldx, epi);
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
     } else if (c.band_fwd && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
-        rc = launch_gemm_band(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, c.kr_fwd.as<int>(), epi);
+        rc = band_variant() == 2
+                 ? launch_gemm_band2(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, c.kr_fwd.as<int>(), epi)
+                 : launch_gemm_band(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, c.kr_fwd.as<int>(), epi);
     else if (use_dlds() && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
         rc = launch_gemm_dlds(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
     else
@@ -426,7 +437,9 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
                            h.S.d(), h.S.ld, epi);
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
     } else if (c.band_bwd && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
-        rc = launch_gemm_band(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, c.kr_bwd.as<int>(), epi);
+        rc = band_variant() == 2
+                 ? launch_gemm_band2(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, c.kr_bwd.as<int>(), epi)
+                 : launch_gemm_band(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, c.kr_bwd.as<int>(), epi);
     else if (use_dlds() && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
         rc = launch_gemm_dlds(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
     else

@@ -168,6 +168,165 @@ __global__ __launch_bounds__(512) void dgemm_dlds_kernel(GemmP p, Epi epi)
     epi(acc, m0 + wr * 80, n0 + wc * 32, lane, p.M, p.N, bi * 2 + wr);
 }
 
+// ---- the same kernel (K step 16, 3 stages) with hand-scheduled operand reads ------------------
+// As in dgemm_band.h: the compiler's `s_waitcnt lgkmcnt(0)` before every MFMA group also waits for
+// the reads just issued for the next group.  Here the ds_reads go through inline asm, double
+// buffered in registers with counted lgkmcnt(7) waits (5 A + 2 B reads per K substep), and the
+// end-of-tile vmcnt + barrier sits before the last MFMA group of a tile.
+// The XOR-1 block swizzle of the A image depends on the parity of the k row a lane reads (= lk & 1)
+// and on the parity of the block (wr * 5 + i): two per-lane base addresses, compile-time offsets.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DL_RD(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#else
+#define DL_RD(dst, addr, off) (dst = 0.0)
+#endif
+template <int KS>
+__device__ __forceinline__ void dl_read(double (&a)[5], double (&b)[2], unsigned a_i_even, unsigned a_i_odd, unsigned baddr)
+{
+    DL_RD(a[0], a_i_even, KS * 4 * DL_BM * 8);
+    DL_RD(a[1], a_i_odd, KS * 4 * DL_BM * 8 + 128);
+    DL_RD(a[2], a_i_even, KS * 4 * DL_BM * 8 + 256);
+    DL_RD(a[3], a_i_odd, KS * 4 * DL_BM * 8 + 384);
+    DL_RD(a[4], a_i_even, KS * 4 * DL_BM * 8 + 512);
+    DL_RD(b[0], baddr, KS * 2 * DL_BN * 16);
+    DL_RD(b[1], baddr, KS * 2 * DL_BN * 16 + 256);
+}
+template <int LEAVE>
+__device__ __forceinline__ void dl_wait(double (&a)[5], double (&b)[2])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (LEAVE == 7)
+        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b[0]), "+v"(b[1]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b[0]), "+v"(b[1]));
+#endif
+}
+__device__ __forceinline__ void dl_mfma(d4 (&acc)[5][2], const double (&a)[5], const double (&b)[2])
+{
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i], acc[i][j], 0, 0, 0);
+}
+
+template <class Epi>
+__global__ __launch_bounds__(512) void dgemm_dlds_asm_kernel(GemmP p, Epi epi)
+{
+    using Cfg = DlCfg<16, 3>;
+    constexpr int BK = 16, STAGES = 3;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nblk = p.gm * p.gn;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int bi = nid / p.gn, bj = nid - bi * p.gn;
+    const int m0 = bi * DL_BM, n0 = bj * DL_BN;
+
+    const double* pa[Cfg::NA]; int la[Cfg::NA];
+#pragma unroll
+    for (int s = 0; s < Cfg::NA; ++s) {
+        int c = wave + 8 * s;
+        if (c >= Cfg::A_CHUNKS) c = wave + 8;
+        const int o = c * 1024 + lane * 16;
+        const int k = o / (DL_BM * 8), pos = (o - k * DL_BM * 8) >> 3;
+        const int blk = pos >> 4, within = pos & 15;
+        const int m = (((blk ^ (k & 1)) << 4) | within);
+        int gm = m0 + m;
+        if (gm >= p.M) gm = 0;
+        pa[s] = p.A + gm + (size_t)k * p.lda;
+        la[s] = c * 1024;
+    }
+    const double* pb[Cfg::NB]; int lb[Cfg::NB];
+#pragma unroll
+    for (int s = 0; s < Cfg::NB; ++s) {
+        const int c = wave + 8 * s;
+        const int kp = c >> 1, n = ((c & 1) << 6) + lane;
+        int gn = n0 + n;
+        if (gn >= p.N) gn = 0;
+        pb[s] = p.B + 2 * kp + (size_t)gn * p.ldb;
+        lb[s] = Cfg::A_BYTES + c * 1024;
+    }
+    const size_t stepA = (size_t)BK * p.lda;
+    auto issue = [&](int stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        char* base = lds + stage * Cfg::STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < Cfg::NA; ++s) {
+            __builtin_amdgcn_global_load_lds(pa[s], (lds_ptr_t)(base + la[s]), 16, 0, 0);
+            pa[s] += stepA;
+        }
+#pragma unroll
+        for (int s = 0; s < Cfg::NB; ++s) {
+            __builtin_amdgcn_global_load_lds(pb[s], (lds_ptr_t)(base + lb[s]), 16, 0, 0);
+            pb[s] += BK;
+        }
+#else
+        (void)stage; (void)stepA;
+#endif
+    };
+    auto wait_leave = [&](int tiles) {
+        static_assert(Cfg::PER_TILE == 5, "vmcnt immediates below");
+        if (tiles >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (tiles == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    d4 acc[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+    const int l15 = lane & 15, lk = lane >> 4, par = lk & 1;
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)lds;
+    // block wr*5 + i read by a lane of k-parity `par` sits at block (wr*5 + i) ^ par
+    const unsigned abase = lds0 + lk * (DL_BM * 8) + l15 * 8 + wr * 5 * 128;
+    const unsigned a_blk_even = abase + par * 128, a_blk_odd = abase - par * 128;       // for even / odd block index
+    const unsigned a_i_even = (wr & 1) ? a_blk_odd : a_blk_even;                         // parity of wr*5 + i, i even
+    const unsigned a_i_odd = (wr & 1) ? a_blk_even : a_blk_odd;
+    const unsigned boff = lds0 + Cfg::A_BYTES + (lk >> 1) * (DL_BN * 16) + wc * 512 + l15 * 16 + par * 8;
+
+    const int nk = (p.K + BK - 1) / BK;
+    int issued = 0;
+    for (; issued < STAGES - 1 && issued < nk; ++issued) issue(issued);
+    wait_leave(issued - 1);
+    __builtin_amdgcn_s_barrier();
+    int st = 0;
+    double ra[2][5], rb[2][2];
+    dl_read<0>(ra[0], rb[0], a_i_even, a_i_odd, boff);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (issued < nk) {
+            int sn = st + STAGES - 1; if (sn >= STAGES) sn -= STAGES;
+            issue(sn);
+            ++issued;
+        }
+        const unsigned so = st * Cfg::STAGE_BYTES;
+        int stn = st + 1; if (stn >= STAGES) stn = 0;
+#define DL_STEP(KS, CUR, NXT)                                                            \
+        dl_read<KS + 1>(ra[NXT], rb[NXT], a_i_even + so, a_i_odd + so, boff + so);         \
+        dl_wait<7>(ra[CUR], rb[CUR]);                                                      \
+        dl_mfma(acc, ra[CUR], rb[CUR]);                                                    \
+        __builtin_amdgcn_sched_barrier(0);
+        DL_STEP(0, 0, 1) DL_STEP(1, 1, 0) DL_STEP(2, 0, 1)
+#undef DL_STEP
+        wait_leave(issued - kt - 2);
+        dl_wait<0>(ra[1], rb[1]);
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) {
+            const unsigned sn2 = stn * Cfg::STAGE_BYTES;
+            dl_read<0>(ra[0], rb[0], a_i_even + sn2, a_i_odd + sn2, boff + sn2);
+        }
+        dl_mfma(acc, ra[1], rb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        st = stn;
+    }
+    epi(acc, m0 + wr * 80, n0 + wc * 32, lane, p.M, p.N, bi * 2 + wr);
+}
+
 // Host contract of the direct-to-LDS kernel; returns false when the generic kernel must be used.
 static inline bool dlds_applicable(int M, int N, int K, const double* A, int lda, int a_cols_alloc,
                                    const double* B, int ldb)
@@ -197,9 +356,22 @@ static inline int launch_gemm_dlds(hipStream_t s, int M, int N, int K, const dou
                                    const double* B, int ldb, const Epi& epi)
 {
     GemmP p{M, N, K, A, lda, B, ldb, (M + DL_BM - 1) / DL_BM, (N + DL_BN - 1) / DL_BN, 0, 0};
+    // GLMMR_MCML_DLDS: 0 = hand-scheduled reads (default), 1 = (32, 2) compiler-scheduled, 2 = (16, 3) compiler-scheduled
     static const int variant = getenv("GLMMR_MCML_DLDS") ? atoi(getenv("GLMMR_MCML_DLDS")) : 0;
     if (variant == 1) return launch_gemm_dlds_cfg<32, 2, Epi>(s, p, epi);
-    return launch_gemm_dlds_cfg<16, 3, Epi>(s, p, epi);
+    if (variant == 2) return launch_gemm_dlds_cfg<16, 3, Epi>(s, p, epi);
+    {
+        using Cfg = DlCfg<16, 3>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            MCML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dgemm_dlds_asm_kernel<Epi>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((dgemm_dlds_asm_kernel<Epi>), dim3(p.gm * p.gn), dim3(512), Cfg::LDS_BYTES, s, p, epi);
+        MCML_HIP(hipGetLastError());
+        return MCML_OK;
+    }
 }
 
 }  // namespace mcml

@@ -51,6 +51,10 @@ const char* last_error();
         }                                    \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that needs more than 64 KB of LDS: set once per
+// (kernel, device) -- a process may hold contexts on several GPUs
+int ensure_dynamic_lds(const void* kernel, int bytes);
+
 static inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
 static inline size_t round_up_sz(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -1,7 +1,25 @@
 // common.hip -- error string, matrix upload/download.
 #include "common.h"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace mcml {
+
+int ensure_dynamic_lds(const void* kernel, int bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    MCML_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({kernel, dev})) return MCML_OK;
+    MCML_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({kernel, dev});
+    return MCML_OK;
+}
+
 
 static thread_local std::string g_err;
 

@@ -315,12 +315,7 @@ static inline int launch_gemm_band(hipStream_t s, int M, int N, int K, const dou
     bp.krange = krange;
     bp.nbands = (M + BD_BM - 1) / BD_BM;
     const int npairs = (bp.nbands + 1) / 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MCML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dgemm_band_kernel<Epi>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)BD_LDS_BYTES));
-        attr_set = true;
-    }
+    MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&dgemm_band_kernel<Epi>), (int)BD_LDS_BYTES));
     hipLaunchKernelGGL((dgemm_band_kernel<Epi>), dim3(npairs * bp.g.gn), dim3(512), BD_LDS_BYTES, s, bp, epi);
     MCML_HIP(hipGetLastError());
     return MCML_OK;

@@ -156,12 +156,7 @@ static inline int launch_gemm_band2(hipStream_t s, int M, int N, int K, const do
     bp.krange = krange;
     bp.nbands = (M + BD_BM - 1) / BD_BM;
     const int npairs = (bp.nbands + 1) / 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MCML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dgemm_band2_kernel<Epi>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)B2_LDS_BYTES));
-        attr_set = true;
-    }
+    MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&dgemm_band2_kernel<Epi>), (int)B2_LDS_BYTES));
     hipLaunchKernelGGL((dgemm_band2_kernel<Epi>), dim3(npairs * bp.g.gn), dim3(256), B2_LDS_BYTES, s, bp, epi);
     MCML_HIP(hipGetLastError());
     return MCML_OK;

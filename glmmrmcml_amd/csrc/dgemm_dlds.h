@@ -340,12 +340,7 @@ template <int BK, int STAGES, class Epi>
 static inline int launch_gemm_dlds_cfg(hipStream_t s, const GemmP& p, const Epi& epi)
 {
     using Cfg = DlCfg<BK, STAGES>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MCML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dgemm_dlds_kernel<BK, STAGES, Epi>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
-        attr_set = true;
-    }
+    MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&dgemm_dlds_kernel<BK, STAGES, Epi>), (int)Cfg::LDS_BYTES));
     hipLaunchKernelGGL((dgemm_dlds_kernel<BK, STAGES, Epi>), dim3(p.gm * p.gn), dim3(512), Cfg::LDS_BYTES, s, p, epi);
     MCML_HIP(hipGetLastError());
     return MCML_OK;
@@ -362,12 +357,7 @@ static inline int launch_gemm_dlds(hipStream_t s, int M, int N, int K, const dou
     if (variant == 2) return launch_gemm_dlds_cfg<16, 3, Epi>(s, p, epi);
     {
         using Cfg = DlCfg<16, 3>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            MCML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dgemm_dlds_asm_kernel<Epi>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
-            attr_set = true;
-        }
+        MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&dgemm_dlds_asm_kernel<Epi>), (int)Cfg::LDS_BYTES));
         hipLaunchKernelGGL((dgemm_dlds_asm_kernel<Epi>), dim3(p.gm * p.gn), dim3(512), Cfg::LDS_BYTES, s, p, epi);
         MCML_HIP(hipGetLastError());
         return MCML_OK;

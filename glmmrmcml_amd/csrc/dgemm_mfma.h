@@ -340,13 +340,9 @@ static inline int launch_gemm_tile(hipStream_t s, GemmP p, const Epi& epi)
     using Cfg = GemmCfg<WTM, WTN, WM, WN, BNMAJOR, BK>;
     p.gm = (p.M + Cfg::BM - 1) / Cfg::BM;
     p.gn = (p.N + Cfg::BN - 1) / Cfg::BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MCML_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&dgemm_mfma_kernel<WTM, WTN, WM, WN, BNMAJOR, BK, STAGGER, INNER, Epi>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES));
-        attr_set = true;
-    }
+    MCML_TRY(ensure_dynamic_lds(
+        reinterpret_cast<const void*>(&dgemm_mfma_kernel<WTM, WTN, WM, WN, BNMAJOR, BK, STAGGER, INNER, Epi>),
+        (int)Cfg::LDS_BYTES));
     hipLaunchKernelGGL((dgemm_mfma_kernel<WTM, WTN, WM, WN, BNMAJOR, BK, STAGGER, INNER, Epi>), dim3(p.gm * p.gn),
                        dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, p, epi);
     MCML_HIP(hipGetLastError());

@@ -589,6 +589,13 @@ struct LaFit {
     }
 };
 
+// the Laplace path forces the dense ZL and leaves c.L at an arbitrary theta: restore / invalidate on every exit
+struct LaScope {
+    Ctx& c;
+    explicit LaScope(Ctx& ctx) : c(ctx) {}
+    ~LaScope() { c.no_sparse_zl = false; c.have_L = false; }
+};
+
 // ------------------------------------------------------------------ entry points (cabi.hip)
 int drv_la(Ctx& c, const double* start, int nstart, int nr, int usehess, double tol, int verbose, int trace,
            int maxiter, const glmmr_mcml_ext* e, double* beta, double* theta, double* sigma, double* se, double* u,
@@ -597,14 +604,12 @@ int drv_la(Ctx& c, const double* start, int nstart, int nr, int usehess, double 
     MCML_REQUIRE(c.n > 0 && c.cov.npar > 0, "mcml_la: the context has no model / covariance");
     MCML_REQUIRE(start && nstart >= c.P + c.cov.npar + (la_is_gaussian(c.flink) ? 1 : 0), "mcml_la: start too short");
     MCML_REQUIRE(beta && theta && sigma, "mcml_la: null output");
+    LaScope scope(c);
     LaFit f(c);
     f.trace = trace;
     f.maxfun = (e && e->maxfun > 0) ? e->maxfun : 0;
     MCML_TRY(f.init(start));
-    int rc = f.run(nr != 0, usehess != 0, tol, maxiter, verbose, beta, theta, sigma, se, nstart, u, converged, iters);
-    c.no_sparse_zl = false;
-    c.have_L = false;                       // c.L no longer belongs to a theta the caller knows
-    return rc;
+    return f.run(nr != 0, usehess != 0, tol, maxiter, verbose, beta, theta, sigma, se, nstart, u, converged, iters);
 }
 
 // test hook: one functor value / one mcnr_b step from a given state (see include/glmmr_mcml_c.h)
@@ -613,6 +618,7 @@ int drv_la_probe(Ctx& c, const double* start, int nstart, int kind, const double
 {
     MCML_REQUIRE(c.n > 0 && c.cov.npar > 0, "la_probe: the context has no model / covariance");
     MCML_REQUIRE(start && nstart >= c.P + c.cov.npar, "la_probe: start too short");
+    LaScope scope(c);
     LaFit f(c);
     MCML_TRY(f.init(start));
     f.var_par = var_par;
@@ -631,8 +637,6 @@ int drv_la_probe(Ctx& c, const double* start, int nstart, int kind, const double
             *sigma_out = f.sigma;
         }
     }
-    c.no_sparse_zl = false;
-    c.have_L = false;
     return rc;
 }
 

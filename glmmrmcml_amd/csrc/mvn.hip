@@ -418,8 +418,7 @@ int potrf_leaf_profile(Ctx& c, unsigned long long* host10)
     std::vector<double> h((size_t)A.ld * 128, 0.0);
     for (int j = 0; j < 128; ++j) for (int i = 0; i < 128; ++i) h[i + (size_t)j * A.ld] = (i == j ? 130.0 : 1.0 / (1 + abs(i - j)));
     MCML_HIP(hipMemcpy(A.d(), h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
-    MCML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_leaf), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(sizeof(double) * (128 * 129 + 128 + 7 * 256))));
+    MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_potrf_leaf), (int)(sizeof(double) * (128 * 129 + 128 + 7 * 256))));
     for (int rep = 0; rep < 3; ++rep) {
         MCML_HIP(hipMemcpy(A.d(), h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(LEAF_NT), sizeof(double) * (128 * 129 + 128 + 7 * 256), c.stream, A.d(), A.ld,
@@ -645,12 +644,7 @@ int potrf_lower(Ctx& c, double* A, int n, int lda)
 {
     MCML_REQUIRE(n > 0 && lda >= n && (lda & 1) == 0, "potrf: bad shape n=%d lda=%d", n, lda);
     MCML_TRY(c.linv.ensure(sizeof(double) * (size_t)(n / CHOL_NB + 1) * CHOL_NB * CHOL_NB));
-    static bool attr = false;
-    if (!attr) {
-        MCML_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_leaf),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_LDS));
-        attr = true;
-    }
+    MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_potrf_leaf), (int)POTRF_LDS));
     if (chol_blocked()) return potrf_blocked(c, A, lda, n);
     return potrf_rec(c, A, lda, 0, n);
 }

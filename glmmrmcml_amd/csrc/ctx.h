@@ -40,28 +40,43 @@ struct SparseZL {
 // (bench.py's roofline line).  kind 0 = HMC forward GEMM, 1 = HMC backward GEMM.
 struct KernelProf {
     bool on = false;
-    std::vector<hipEvent_t> ev;
-    std::vector<int> kind;
-    size_t used = 0;
+    std::vector<hipEvent_t> ev;                 // pool
+    std::vector<int> kind, e0, e1;              // per timed launch: kind, start / stop event index
+    size_t used = 0, nev = 0;
+    int last_stop = -1;                         // event recorded right after the previous timed launch
     double ms[4] = {0, 0, 0, 0};
     long long cnt[4] = {0, 0, 0, 0};
-    int begin(hipStream_t s, int k) {
-        if (!on) return -1;
-        if (2 * used + 1 >= ev.size()) {
+    int fresh() {
+        if (nev >= ev.size())
             for (int i = 0; i < 512; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return -1; ev.push_back(e); }
-            kind.resize(ev.size() / 2);
-        }
-        kind[used] = k;
-        (void)hipEventRecord(ev[2 * used], s);
+        return (int)nev++;
+    }
+    // chain = true: this launch directly follows the previous timed launch on the same stream, so that
+    // launch's stop marker doubles as this one's start (one marker per kernel instead of two: every
+    // marker costs a few microseconds of idle GPU between dependent kernels)
+    int begin(hipStream_t s, int k, bool chain = false) {
+        if (!on) return -1;
+        int st = (chain && last_stop >= 0) ? last_stop : fresh();
+        if (st < 0) return -1;
+        if (!(chain && last_stop >= 0)) (void)hipEventRecord(ev[st], s);
+        if (used >= kind.size()) { kind.resize(used + 512); e0.resize(used + 512); e1.resize(used + 512); }
+        kind[used] = k; e0[used] = st; e1[used] = -1;
         return (int)used++;
     }
-    void end(hipStream_t s, int slot) { if (slot >= 0) (void)hipEventRecord(ev[2 * slot + 1], s); }
+    void end(hipStream_t s, int slot) {
+        if (slot < 0) return;
+        const int sp = fresh();
+        if (sp < 0) return;
+        (void)hipEventRecord(ev[sp], s);
+        e1[slot] = sp; last_stop = sp;
+    }
+    void unchain() { last_stop = -1; }          // something else was launched in between
     void collect() {       // call after the stream has been synchronised
         for (size_t i = 0; i < used; ++i) {
             float t = 0;
-            if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) == hipSuccess) { ms[kind[i]] += t; cnt[kind[i]] += 1; }
+            if (e1[i] >= 0 && hipEventElapsedTime(&t, ev[e0[i]], ev[e1[i]]) == hipSuccess) { ms[kind[i]] += t; cnt[kind[i]] += 1; }
         }
-        used = 0;
+        used = 0; nev = 0; last_stop = -1;
     }
     ~KernelProf() { for (auto e : ev) (void)hipEventDestroy(e); }
 };

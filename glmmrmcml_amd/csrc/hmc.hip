@@ -394,11 +394,11 @@ static int band_variant()
 }
 
 // MU = xb + ZL * X ; S = score
-static int hmc_forward(Ctx& c, const double* X, int ldx, bool store_mu = true)
+static int hmc_forward(Ctx& c, const double* X, int ldx, bool store_mu = true, bool chain = false)
 {
     HmcState& h = c.hmc;
     EpiForward epi{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink, store_mu ? 1 : 0};
-    const int slot = c.prof.begin(c.stream, 0);
+    const int slot = c.prof.begin(c.stream, 0, chain);
     int rc;
     if (c.sp.active) {
         const int gy = h.C < 256 ? h.C : 256;
@@ -417,12 +417,12 @@ static int hmc_forward(Ctx& c, const double* X, int ldx, bool store_mu = true)
     return rc;
 }
 
-static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_par, int mode)
+static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_par, int mode, bool chain = false)
 {
     HmcState& h = c.hmc;
     ChainArrays ca = chain_arrays(h);
     EpiBackward epi{Xs, G, h.R.d(), h.UP.d(), h.V.ld, ca.e, ca.steps, s, glm_score_post(var_par, c.flink), mode};
-    const int slot = c.prof.begin(c.stream, 1);
+    const int slot = c.prof.begin(c.stream, 1, chain);
     int rc;
     if (c.sp.active && c.sp.nnz >= 24L * c.Q) {
         int gy = (h.C + 3) / 4; if (gy > 64) gy = 64;
@@ -515,9 +515,10 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         MCML_HIP(hipStreamSynchronize(c.stream));
         MCML_REQUIRE(maxs >= 1 && maxs <= o->max_steps, "hmc: step count %d out of range", maxs);
         for (int s = 0; s < maxs; ++s) {
-            MCML_TRY(hmc_forward(c, h.UP.d(), h.UP.ld, s == maxs - 1));
-            MCML_TRY(hmc_backward(c, h.UP.d(), h.GRADP.d(), s, var_par, 1));
+            MCML_TRY(hmc_forward(c, h.UP.d(), h.UP.ld, s == maxs - 1, s > 0));
+            MCML_TRY(hmc_backward(c, h.UP.d(), h.GRADP.d(), s, var_par, 1, true));
         }
+        c.prof.unchain();
         const int adapt = (it < o->warmup) && (it < o->adapt);     // mhmcmc.h:131-136
         hipLaunchKernelGGL(k_hmc_accept, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(), h.UP.d(),
                            h.GRADP.d(), h.V.ld, Q, h.MU.d(), h.MU.ld, n, c.y.d(), var_par, c.flink, ca,

@@ -19,6 +19,7 @@
 #include "ctx.h"
 #include "dgemm_mfma.h"
 #include "dgemm_dl.h"
+#include "dgemm_dlds.h"
 #include "reduce.h"
 
 namespace mcml {
@@ -649,27 +650,36 @@ int potrf_lower(Ctx& c, double* A, int n, int lda)
     return potrf_rec(c, A, lda, 0, n);
 }
 
-// U (n x m) <- inv(L) U, L = A0[off.., off..]; needs the leaf inverses potrf_lower left in c.linv
+// U (n x m) <- inv(L) U, L = A0[off.., off..]; needs the leaf inverses potrf_lower left in c.linv.
+// Recursive splitting: the update U2 -= L21 U1 is ONE product with K = n/2, n/4, ... (long-K GEMMs
+// at full MFMA efficiency) instead of n/128 products with K = 128.
 static int trsm_left_rec(Ctx& c, const double* A0, int lda, int off, int n, double* U, int ldu, int m)
 {
     if (n <= CHOL_NB) {
         const double* Linv = c.linv.d() + (size_t)(off / CHOL_NB) * CHOL_NB * CHOL_NB;
         EpiAxpby epi{U, ldu, 1.0, 0.0};
         // in place: a workgroup reads its whole column band (K = n <= 128) before it writes
-        return launch_gemm<false>(c.stream, n, m, n, Linv, CHOL_NB, U, ldu, epi, false, 1);
+        return chol_gemm<false>(c.stream, n, m, n, Linv, CHOL_NB, U, ldu, epi, false, 2);
     }
     const int n1 = split128(n), n2 = n - n1;
     MCML_TRY(trsm_left_rec(c, A0, lda, off, n1, U, ldu, m));
     const double* L21 = A0 + (off + n1) + (size_t)off * lda;
     double* U2 = U + n1;
     EpiAxpby epi{U2, ldu, -1.0, 1.0};
-    MCML_TRY(launch_gemm<false>(c.stream, n2, m, n1, L21, lda, U, ldu, epi));
+    static const bool big_dlds = getenv("GLMMR_MCML_TRSM_BIG") && !strcmp(getenv("GLMMR_MCML_TRSM_BIG"), "dlds");
+    if (big_dlds && n1 > CHOL_NB && dlds_applicable(n2, m, n1, L21, lda, n1 + 32, U, ldu))
+        MCML_TRY(launch_gemm_dlds(c.stream, n2, m, n1, L21, lda, U, ldu, epi));
+    else
+        MCML_TRY(chol_gemm<false>(c.stream, n2, m, n1, L21, lda, U, ldu, epi, false, 0));
     return trsm_left_rec(c, A0, lda, off + n1, n2, U2, ldu, m);
 }
 
 int trsm_left_lower(Ctx& c, const double* L, int ldl, int n, double* U, int ldu, int m)
 {
-    if (chol_blocked()) return trsm_left_blocked(c, L, ldl, n, U, ldu, m);
+    // GLMMR_MCML_TRSM=rec: the recursive variant (long-K updates; measured 3-15 % slower at Q = 5000, m = 1024
+    // than the panel-by-panel one with the two-per-CU K = 128 tiles)
+    static const bool rec = getenv("GLMMR_MCML_TRSM") && !strcmp(getenv("GLMMR_MCML_TRSM"), "rec");
+    if (chol_blocked() && !(rec && m >= 64)) return trsm_left_blocked(c, L, ldl, n, U, ldu, m);
     return trsm_left_rec(c, L, ldl, 0, n, U, ldu, m);
 }
 

@@ -197,3 +197,46 @@ def test_LA_dispatch_and_table():
     assert "Laplace Approximation" in str(f1)
     with pytest.raises(ValueError):
         m.LA(d["y"], method="bfgs")
+
+
+# Printed coefficient tables of the reference's own README (README.md:56-64, 89-97, 144-147; the fits themselves are
+# not reproducible here -- R's RNG simulated the data).  They pin the post-processing print.mcml applies to
+# (estimate, SE): z = est / SE, two-sided normal p, est -+ qnorm(0.975) SE.  All figures are rounded to 2 decimals in
+# the README, so the comparison allows the rounding of the inputs to propagate.
+README_ROWS = [
+    # name, Estimate, Std. Err., z value, p value, 2.5% CI, 97.5% CI
+    ("int", 0.59, 0.23, 2.57, 0.01, 0.14, 1.04), ("t1", -1.51, 0.27, -5.50, 0.00, -2.04, -0.97),
+    ("t2", -1.18, 0.26, -4.55, 0.00, -1.69, -0.67), ("t3", -1.23, 0.26, -4.70, 0.00, -1.74, -0.72),
+    ("t4", 1.61, 0.30, 5.29, 0.00, 1.01, 2.20), ("t5", -2.57, 0.36, -7.21, 0.00, -3.26, -1.87),
+    ("1 | gr(cl)", 0.62, 0.14, 4.47, 0.00, 0.35, 0.89),
+    ("int", 0.91, 0.23, 3.90, 0, 0.45, 1.37), ("t4", 1.44, 0.31, 4.69, 0, 0.84, 2.04),
+    ("1 | gr(cl) * ar1(t).1", 0.79, 0.11, 7.22, 0, 0.58, 1.01), ("1 | gr(cl) * ar1(t).2", 0.62, 0.12, 5.31, 0, 0.39, 0.85),
+    ("(Intercept)", 0.86, 0.06, 13.91, 0, 0.74, 0.99), ("1 | fexp(x, y).1", 0.26, 0.02, 10.57, 0, 0.21, 0.31),
+]
+
+
+def test_print_table_formulas_against_the_reference_readme():
+    from glmmrmcml_amd.model import McmlFit
+    est = np.array([r[1] for r in README_ROWS]); se = np.array([r[2] for r in README_ROWS])
+    fit = McmlFit(coefficients=dict(par=[r[0] for r in README_ROWS] + ["d1"], est=np.r_[est, 0.0], SE=np.r_[se, np.nan],
+                                    lower=np.r_[est - 1.959963984540054 * se, np.nan],
+                                    upper=np.r_[est + 1.959963984540054 * se, np.nan]),
+                  re_samps=np.zeros((1, 3)), method="mcnr", sim_lik=False, family="binomial", link="logit", m=250,
+                  tol=0.005, aic=422.04, Rsq=dict(cond=0.24, marg=0.21), converged=True)
+    rows = fit.table()
+    assert len(rows) == len(README_ROWS)
+    for got, want in zip(rows, README_ROWS):
+        e, s = want[1], want[2]
+        # inputs are known to +-0.005: propagate that into each derived figure, plus the README's own rounding
+        dz = abs(e) / s * (0.005 / abs(e) + 0.005 / s) + 0.006
+        assert abs(got[3] - want[3]) <= dz, (want[0], got[3], want[3])
+        assert abs(got[4] - want[4]) <= 0.006
+        assert abs(got[5] - want[5]) <= 0.005 + 1.96 * 0.005 + 0.006
+        assert abs(got[6] - want[6]) <= 0.005 + 1.96 * 0.005 + 0.006
+    txt = str(fit)
+    # the same header / footer lines the README prints (README.md:53-67)
+    assert "Number of Monte Carlo simulations per iteration: 250 with tolerance 0.005" in txt
+    assert "cAIC: 422.04" in txt and "Approximate R-squared: Conditional: 0.24  Marginal: 0.21" in txt
+    # duplicated names get .1 / .2 suffixes as print.mcml does
+    names = [r[0] for r in rows]
+    assert names.count("int.1") == 1 and names.count("int.2") == 1 and names.count("t4.1") == 1

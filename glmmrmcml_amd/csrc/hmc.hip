@@ -504,15 +504,47 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         hipLaunchKernelGGL(k_hmc_store, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.V.ld, Q, samp.d(), samp.ld, 0, 0);
 
     int* d_maxs = c.scalars.as<int>() + 34;
+    // The number of leapfrog iterations to launch is the largest step count over the chains, a device
+    // value.  Reading it back costs a host synchronisation per proposal (~50 us of idle GPU).  While
+    // the step counts observed so far sit at the cap (lambda / e >= max_steps, the usual regime), the
+    // cap itself is launched without waiting -- iterations beyond a chain's own count are masked
+    // no-ops, so results are identical -- and the true value is read back asynchronously (pinned
+    // ring, 4 proposals deep); an observation below the cap switches back to the exact, synchronous
+    // path.  GLMMR_MCML_HMC_SPEC=0 disables the speculation.
+    static const bool spec_allowed = !(getenv("GLMMR_MCML_HMC_SPEC") && atoi(getenv("GLMMR_MCML_HMC_SPEC")) == 0);
+    constexpr int RING = 4;
+    int* h_ring = nullptr;
+    hipEvent_t ring_ev[RING];
+    bool ring_busy[RING] = {false, false, false, false};
+    MCML_HIP(hipHostMalloc((void**)&h_ring, sizeof(int) * RING));
+    for (int i = 0; i < RING; ++i) MCML_HIP(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming));
+    struct RingGuard {
+        int* p; hipEvent_t* ev; int n; hipStream_t s;
+        ~RingGuard() { (void)hipStreamSynchronize(s); for (int i = 0; i < n; ++i) (void)hipEventDestroy(ev[i]); (void)hipHostFree(p); }
+    } ring_guard{h_ring, ring_ev, RING, c.stream};
+    int seen_maxs = -1;                         // latest step count actually observed
     for (int it = 0; it < total; ++it) {
         hipLaunchKernelGGL(k_hmc_propose, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(), h.UP.d(),
                            h.V.ld, Q, ca, o->lambda, o->max_steps, seed, (uint32_t)o->chain_offset, iter_idx, it,
                            p_mom, C);
         hipLaunchKernelGGL(k_max_steps, dim3(1), dim3(256), 0, c.stream, ca.steps, C, d_maxs);
         MCML_HIP(hipGetLastError());
+        for (int i = 0; i < RING; ++i)          // harvest finished read-backs
+            if (ring_busy[i] && hipEventQuery(ring_ev[i]) == hipSuccess) { seen_maxs = h_ring[i]; ring_busy[i] = false; }
         int maxs = 0;
-        MCML_HIP(hipMemcpyAsync(&maxs, d_maxs, sizeof(int), hipMemcpyDeviceToHost, c.stream));
-        MCML_HIP(hipStreamSynchronize(c.stream));
+        if (spec_allowed && seen_maxs == o->max_steps) {
+            const int slot = it % RING;
+            if (ring_busy[slot]) { MCML_HIP(hipEventSynchronize(ring_ev[slot])); seen_maxs = h_ring[slot]; ring_busy[slot] = false; }
+            MCML_HIP(hipMemcpyAsync(h_ring + slot, d_maxs, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+            MCML_HIP(hipEventRecord(ring_ev[slot], c.stream));
+            ring_busy[slot] = true;
+            maxs = o->max_steps;
+        } else {
+            MCML_HIP(hipMemcpyAsync(&maxs, d_maxs, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+            MCML_HIP(hipStreamSynchronize(c.stream));
+            for (int i = 0; i < RING; ++i) ring_busy[i] = false;     // everything older has completed
+            seen_maxs = maxs;
+        }
         MCML_REQUIRE(maxs >= 1 && maxs <= o->max_steps, "hmc: step count %d out of range", maxs);
         for (int s = 0; s < maxs; ++s) {
             MCML_TRY(hmc_forward(c, h.UP.d(), h.UP.ld, s == maxs - 1, s > 0));

@@ -232,9 +232,29 @@ __device__ __forceinline__ double chain_log_prob(const double* MU, int ldm, int 
                                                  int Q, const double* y, double var_par, int flink, int c,
                                                  double* sh)
 {
+    // loads batched four deep (the kernel is latency-bound: 4 workgroups per CU); each thread still adds its
+    // own elements in index order, so the sums are bit-identical to the plain loop
     double ll = 0, lp = 0;
-    for (int i = threadIdx.x; i < n; i += 256) ll += glm_logpdf(y[i], MU[i + (size_t)c * ldm], var_par, flink);
-    for (int k = threadIdx.x; k < Q; k += 256) lp += glm_logpdf(X[k + (size_t)c * ldx], 0, 1, 7);
+    for (int i0 = threadIdx.x; i0 < n; i0 += 1024) {
+        double m4[4], y4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            m4[u] = i < n ? MU[i + (size_t)c * ldm] : 0.0;
+            y4[u] = i < n ? y[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + 256 * u < n) ll += glm_logpdf(y4[u], m4[u], var_par, flink);
+    }
+    for (int k0 = threadIdx.x; k0 < Q; k0 += 1024) {
+        double x4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int k = k0 + 256 * u; x4[u] = k < Q ? X[k + (size_t)c * ldx] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + 256 * u < Q) lp += glm_logpdf(x4[u], 0, 1, 7);
+    }
     double a = block_sum(ll, sh);
     double b = block_sum(lp, sh);
     return a + b;    // valid in thread 0
@@ -303,7 +323,14 @@ __global__ __launch_bounds__(256) void k_hmc_accept(double* V, double* GRAD, con
     const int c = blockIdx.x;
     double l2 = chain_log_prob(MU, ldm, n, UP, ld, Q, y, var_par, flink, c, sh);
     double kin = 0;
-    for (int k = threadIdx.x; k < Q; k += 256) { double r = R[k + (size_t)c * ld]; kin += r * r; }
+    for (int k0 = threadIdx.x; k0 < Q; k0 += 1024) {
+        double r4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int k = k0 + 256 * u; r4[u] = k < Q ? R[k + (size_t)c * ld] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + 256 * u < Q) kin += r4[u] * r4[u];
+    }
     kin = block_sum(kin, sh);
     if (threadIdx.x == 0) {
         const double lprt = 0.5 * kin, lpr = ca.K0[c], l1 = ca.lpcur[c];
@@ -333,10 +360,19 @@ __global__ __launch_bounds__(256) void k_hmc_accept(double* V, double* GRAD, con
     __syncthreads();
     const int acc = acc_s;
     if (acc)
-        for (int k = threadIdx.x; k < Q; k += 256) {
-            const size_t off = k + (size_t)c * ld;
-            V[off] = UP[off];
-            GRAD[off] = GRADP[off];
+        for (int k0 = threadIdx.x; k0 < Q; k0 += 1024) {
+            double u4[4], g4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 256 * u;
+                const size_t off = (k < Q ? k : 0) + (size_t)c * ld;
+                u4[u] = UP[off]; g4[u] = GRADP[off];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 256 * u;
+                if (k < Q) { const size_t off = k + (size_t)c * ld; V[off] = u4[u]; GRAD[off] = g4[u]; }
+            }
         }
 }
 

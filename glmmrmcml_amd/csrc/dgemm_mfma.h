@@ -68,16 +68,31 @@ struct GemmCfg {
 
 struct EpiAxpby {   // C = alpha*A*B + beta*C
     double* C; int ldc; double alpha, beta;
+    // With beta != 0 all reads of C are issued (from clamped, always valid addresses) before the first
+    // store: a store to C followed by a load from C cannot be reordered by the compiler (may alias), so the
+    // straightforward per-element read-modify-write is a chain of dependent memory round trips.
     template <int TM, int TN>
     __device__ __forceinline__ void operator()(d4 (&acc)[TM][TN], int mB, int nB, int lane,
                                                int M, int N, int /*rowslot*/) const {
-        MCML_EPI_FOREACH(TM, TN) {
-            int m = mB + 16 * i + (lane & 15), n = nB + 16 * j + (lane >> 4) + 4 * r;
-            if (m < M && n < N) {
-                double* c = C + m + (size_t)n * ldc;
-                double v = alpha * acc[i][j][r];
-                if (beta != 0.0) v += beta * (*c);
-                *c = v;
+        if (beta != 0.0) {
+            double old[TM][TN][4];
+            MCML_EPI_FOREACH(TM, TN) {
+                int m = mB + 16 * i + (lane & 15), n = nB + 16 * j + (lane >> 4) + 4 * r;
+                const bool ok = m < M && n < N;
+                old[i][j][r] = C[(ok ? m : 0) + (size_t)(ok ? n : 0) * ldc];
+            }
+            MCML_EPI_FOREACH(TM, TN) {
+                int m = mB + 16 * i + (lane & 15), n = nB + 16 * j + (lane >> 4) + 4 * r;
+                if (m < M && n < N) {
+                    double v = alpha * acc[i][j][r];
+                    v += beta * old[i][j][r];
+                    C[m + (size_t)n * ldc] = v;
+                }
+            }
+        } else {
+            MCML_EPI_FOREACH(TM, TN) {
+                int m = mB + 16 * i + (lane & 15), n = nB + 16 * j + (lane >> 4) + 4 * r;
+                if (m < M && n < N) C[m + (size_t)n * ldc] = alpha * acc[i][j][r];
             }
         }
     }

@@ -36,8 +36,17 @@ extern "C" int glmmr_mcml_dbg_dgemm(int M, int N, int K, const double* A, int ld
 }
 
 // times `iters` launches of the M x N x K product on resident random operands
+extern "C" int glmmr_mcml_dbg_dgemm_bench2(int M, int N, int K, int b_nmajor, int iters, int force_tile,
+                                           int lower_only, double beta, double* ms_per_launch);
 extern "C" int glmmr_mcml_dbg_dgemm_bench(int M, int N, int K, int b_nmajor, int iters,
                                           int force_tile, double* ms_per_launch)
+{
+    return glmmr_mcml_dbg_dgemm_bench2(M, N, K, b_nmajor, iters, force_tile, 0, 0.0, ms_per_launch);
+}
+
+// the same with the SYRK-like options of the Cholesky updates: lower tiles only, C read-modify-written
+extern "C" int glmmr_mcml_dbg_dgemm_bench2(int M, int N, int K, int b_nmajor, int iters, int force_tile,
+                                           int lower_only, double beta, double* ms_per_launch)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -55,13 +64,14 @@ extern "C" int glmmr_mcml_dbg_dgemm_bench(int M, int N, int K, int b_nmajor, int
     if (b_nmajor) MCML_TRY(upload_matrix(dB, hB.data(), N, K, N, s));
     else MCML_TRY(upload_matrix(dB, hB.data(), K, N, K, s));
     MCML_TRY(upload_matrix(dC, hC.data(), M, N, M, s));
-    EpiAxpby epi{dC.d(), dC.ld, 1.0, 0.0};
+    EpiAxpby epi{dC.d(), dC.ld, beta != 0.0 ? 1e-3 : 1.0, beta};
+    const bool lo = lower_only != 0;
     auto go = [&]() {
         if (force_tile >= 20)
-            return b_nmajor ? launch_gemm_dl<true>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, false, force_tile - 19)
-                            : launch_gemm_dl<false>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, false, force_tile - 19);
-        return b_nmajor ? launch_gemm<true>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, false, force_tile)
-                        : launch_gemm<false>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, false, force_tile);
+            return b_nmajor ? launch_gemm_dl<true>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, lo, force_tile - 19)
+                            : launch_gemm_dl<false>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, lo, force_tile - 19);
+        return b_nmajor ? launch_gemm<true>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, lo, force_tile)
+                        : launch_gemm<false>(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi, lo, force_tile);
     };
     for (int i = 0; i < 3; i++) MCML_TRY(go());
     hipEvent_t e0, e1;

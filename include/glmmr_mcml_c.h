@@ -264,6 +264,9 @@ int glmmr_mcml_dbg_fd_hessian(glmmr_mcml_objective f, void* user, int n, const d
                               int usebounds, const double* lower, const double* upper, double* H);
 int glmmr_mcml_dbg_dgemm_bench(int M, int N, int K, int b_nmajor, int iters, int force_tile,
                                double* ms_per_launch);
+/* the same with lower tiles only and C read-modify-written (beta != 0), as the Cholesky updates run */
+int glmmr_mcml_dbg_dgemm_bench2(int M, int N, int K, int b_nmajor, int iters, int force_tile, int lower_only,
+                                double beta, double* ms_per_launch);
 /* C = A B through the banded zero-skipping kernel of the sampler (dgemm_band.h); tiles_executed (nullable) =
  * K tiles of 32 actually multiplied, summed over the 80-row bands */
 int glmmr_mcml_dbg_dgemm_band(int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C,

@@ -44,6 +44,13 @@ class HmcDiag(C.Structure):
                 ("max_e", C.c_double), ("max_steps_used", C.c_int), ("leapfrog_total", C.c_longlong)]
 
 
+def rccl_unique_id():
+    """128 opaque bytes from ncclGetUniqueId: made on rank 0, handed to every rank's Context.comm_init_rccl"""
+    buf = (C.c_ubyte * 128)()
+    _lib.check(_lib.lib().glmmr_mcml_rccl_unique_id(buf))
+    return bytes(buf)
+
+
 def _f(a):
     return np.asfortranarray(np.asarray(a, dtype=np.float64))
 
@@ -107,6 +114,16 @@ class Context:
 
     def __exit__(self, *a):
         self.close()
+
+    # -- native multi-GPU exchange (comm.hip): RCCL all-reduce on the context's stream
+    def comm_init_rccl(self, unique_id, rank, world):
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        _lib.check(_lib.lib().glmmr_mcml_ctx_comm_init_rccl(self._h, buf, int(rank), int(world)))
+
+    def comm_stats(self):
+        calls = C.c_longlong(); dbl = C.c_longlong(); nat = C.c_int()
+        _lib.check(_lib.lib().glmmr_mcml_ctx_comm_stats(self._h, C.byref(calls), C.byref(dbl), C.byref(nat)))
+        return dict(calls=calls.value, doubles=dbl.value, native=bool(nat.value))
 
     # -- samples
     def set_u(self, u, niter=None):

@@ -5,7 +5,6 @@
 
 using namespace mcml;
 
-struct glmmr_mcml_ctx { Ctx c; };
 
 namespace mcml {
 int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_opts* o, uint64_t seed,

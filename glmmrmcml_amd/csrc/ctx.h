@@ -4,6 +4,7 @@
 #pragma once
 #include "common.h"
 #include "covspec.h"
+#include "band_plan.h"
 
 namespace mcml {
 
@@ -108,7 +109,8 @@ struct Ctx {
 
     // model state
     DevMat L, ZL, ZLT;          // Q x Q lower factor of D; n x Q; Q x n
-    DevBuf kr_fwd, kr_bwd;      // nonzero K-tile range of every 80-row band of ZL / ZLT (dgemm_band.h)
+    BandPlan plan_fwd, plan_bwd;   // nonzero K-tile range of every 80-row band of ZL / ZLT + the work decomposition (dgemm_band.h)
+    DevBuf kr_scratch;
     bool band_fwd = false, band_bwd = false;   // the structural zeros are worth skipping
     long band_fwd_tiles = 0, band_bwd_tiles = 0;   // sum over bands of the K tiles (of 32) actually multiplied
     DevBuf xb;                  // n
@@ -131,20 +133,29 @@ struct Ctx {
     int rank = 0, world = 1;
     reduce_fn reduce = nullptr;
     void* reduce_user = nullptr;
-    DevBuf reduce_buf;          // doubles handed to the reduce hook
+    void* comm = nullptr;       // ncclComm_t of the native RCCL path (comm.hip); null = hook or single process
+    long long coll_calls = 0, coll_doubles = 0;   // collectives issued / doubles summed (tests, bench)
+    DevBuf reduce_buf;          // doubles handed to the collective
     DevBuf scratch;             // short-lived per-call scratch
 
     // side stream + events for the Cholesky look-ahead (mvn.hip potrf_blocked)
     hipStream_t aux = nullptr;
     hipEvent_t ev_col = nullptr, ev_leaf = nullptr;
     ~Ctx() {
+        comm_release_hook();
         if (ev_col) (void)hipEventDestroy(ev_col);
         if (ev_leaf) (void)hipEventDestroy(ev_leaf);
         if (aux) (void)hipStreamDestroy(aux);
     }
 
     int sync() { MCML_HIP(hipStreamSynchronize(stream)); return MCML_OK; }
+    void comm_release_hook();
 };
+
+// ---- comm.hip ----
+void comm_release(Ctx& c);
+int allreduce_dev(Ctx& c, double* dev, int n);              // in place on device memory, on c.stream
+inline void Ctx::comm_release_hook() { comm_release(*this); }
 
 // ---- mvn.hip ----
 int mvn_setup(Ctx& c);
@@ -161,7 +172,7 @@ int trsm_left_lower(Ctx& c, const double* L, int ldl, int n, double* U, int ldu,
 
 // ---- model.hip ----
 int model_setup(Ctx& c, const double* Z, const double* X, const double* y);
-int allreduce_host(Ctx& c, double* vals, int n);
+int allreduce_host(Ctx& c, double* vals, int n);             // comm.hip
 int model_update_beta(Ctx& c, const double* beta);          // xb = X beta
 int model_update_zu(Ctx& c);                                // ZU = Z U (cached)
 int model_update_L(Ctx& c);                                 // ZL = Z L, ZLT (dense) or the ELL/CSR pair (sparse)
@@ -178,3 +189,6 @@ int hmc_dbg_log_prob_grad(Ctx& c, const double* beta, double var_par, const doub
 int device_sum(Ctx& c, const double* partials, int n, double* dev_out);
 
 }  // namespace mcml
+
+// the opaque handle of include/glmmr_mcml_c.h
+struct glmmr_mcml_ctx { mcml::Ctx c; };

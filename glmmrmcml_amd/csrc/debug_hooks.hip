@@ -117,15 +117,13 @@ extern "C" int glmmr_mcml_dbg_dgemm_band(int M, int N, int K, const double* A, i
     MCML_TRY(kr.ensure(sizeof(int) * 2 * nbands));
     hipLaunchKernelGGL(k_band_ranges, dim3(nbands), dim3(256), 0, s, dA.d(), dA.ld, M, K, kr.as<int>());
     MCML_HIP(hipGetLastError());
-    if (tiles_executed) {
-        std::vector<int> hk(2 * nbands);
-        MCML_HIP(hipMemcpy(hk.data(), kr.p, sizeof(int) * 2 * nbands, hipMemcpyDeviceToHost));
-        int t = 0;
-        for (int b = 0; b < nbands; ++b) t += hk[2 * b + 1] - hk[2 * b];
-        *tiles_executed = t;
-    }
+    std::vector<int> hk(2 * nbands);
+    MCML_HIP(hipMemcpy(hk.data(), kr.p, sizeof(int) * 2 * nbands, hipMemcpyDeviceToHost));
+    BandPlan plan;
+    plan.reset(M, K, hk);
+    if (tiles_executed) *tiles_executed = (int)plan.tiles;
     EpiAxpby epi{dC.d(), dC.ld, 1.0, 0.0};
-    MCML_TRY(launch_gemm_band(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, kr.as<int>(), epi));
+    MCML_TRY(launch_gemm_band(s, plan, N, dA.d(), dA.ld, dB.d(), dB.ld, epi));
     MCML_TRY(download_matrix(C, ldc, dC.d(), dC.ld, M, N, s));
     return MCML_OK;
 }
@@ -162,17 +160,18 @@ extern "C" int glmmr_mcml_dbg_band_clocks(int M, int N, int iters, int mode, dou
     hipLaunchKernelGGL(k_band_ranges, dim3(nbands), dim3(256), 0, s, dA.d(), dA.ld, M, M, kr.as<int>());
     std::vector<int> hk(2 * nbands);
     MCML_HIP(hipMemcpy(hk.data(), kr.p, sizeof(int) * 2 * nbands, hipMemcpyDeviceToHost));
-    double tiles = 0;
-    for (int b = 0; b < nbands; ++b) tiles += hk[2 * b + 1] - hk[2 * b];
+    BandPlan plan;
+    plan.reset(M, M, hk);
+    const double tiles = (double)plan.tiles;
     EpiAxpby epi{dC.d(), dC.ld, 1.0, 0.0};
     for (int i = 0; i < 3; i++)
-        MCML_TRY(launch_gemm_band(s, M, N, M, dA.d(), dA.ld, dB.d(), dB.ld, kr.as<int>(), epi));
+        MCML_TRY((launch_gemm_band<EpiAxpby, true>(s, plan, N, dA.d(), dA.ld, dB.d(), dB.ld, epi)));
     hipEvent_t e0, e1;
     MCML_HIP(hipEventCreate(&e0));
     MCML_HIP(hipEventCreate(&e1));
     MCML_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < iters; i++)
-        MCML_TRY(launch_gemm_band(s, M, N, M, dA.d(), dA.ld, dB.d(), dB.ld, kr.as<int>(), epi, clk.as<unsigned long long>(), mode));
+        MCML_TRY((launch_gemm_band<EpiAxpby, true>(s, plan, N, dA.d(), dA.ld, dB.d(), dB.ld, epi, clk.as<unsigned long long>(), mode)));
     MCML_HIP(hipEventRecord(e1, s));
     MCML_HIP(hipEventSynchronize(e1));
     float ms = 0;

@@ -1,41 +1,44 @@
-// dgemm_band.h -- the HMC products with structural-zero skipping.
+// dgemm_band.h -- the HMC products with structural-zero skipping, any number of chains.
 //
 // For the geospatial designs Z = I, so ZL = L is lower triangular (and ZL' upper): half of
 // the K tiles a dense GEMM multiplies are exactly zero.  More generally, whenever the rows of
 // ZL (or ZL') touch only a range of columns, the products outside that range contribute
 // nothing.  When L is refreshed, k_band_ranges records for every 80-row band of the A operand
-// the first and last K tile that holds a nonzero; this kernel then runs each band's K loop
-// over that range only.
+// the first and last K tile that holds a nonzero; the kernel runs each band's K loop over that
+// range only.  Skipping exact zeros does not change any sum (0*x adds nothing for finite x).
 //
-// Load balance: a workgroup owns TWO bands of one column tile, band p and its mirror
-// nbands-1-p, processed back to back, so for a triangular operand every workgroup executes the
-// same number of K steps.  63 bands x 8 column tiles -> 32 x 8 = 256 workgroups (one per CU)
-// for the 5000 x 1024 products.
+// Work decomposition (BandPlan, built on the host per number of column tiles):
+//   * paired: a workgroup owns band p and its mirror nbands-1-p of one column tile, back to
+//     back, so for a triangular operand every workgroup executes the same number of K steps:
+//     63 bands x 8 column tiles -> 32 x 8 = 256 workgroups (one per CU) for the 5000 x 1024
+//     products.  No partial sums.
+//   * streamed (few column tiles: a rank of the chain-sharded job holds 1024/8 = 128 chains = ONE
+//     column tile, which paired would run on 32 of the 256 CUs): the (band, K tile) iteration
+//     space of a column tile is flattened and cut into equal runs of K tiles, one run per
+//     workgroup, ~256 workgroups in all.  A run may end one band and start the next.  A band
+//     covered by one run is finished by that workgroup; a band cut into several pieces has each
+//     piece stored as a raw accumulator tile (in register order: 512-byte coalesced stores) and
+//     k_band_reduce sums the pieces IN K ORDER and applies the same epilogue functor -- a
+//     fixed-order two-stage reduction, bit-reproducible for a given (operand, chain count).
 //
 // Same direct-to-LDS machinery as dgemm_dlds.h: 80 x 128 tile, 8 waves (each a 80 x 16 strip =
 // 5 x 1 v_mfma_f64_16x16x4 tiles), K step 32, 3-stage LDS ring (156 KB), counted vmcnt + raw
 // barriers.  The A image [k][80 doubles] has 640-byte rows = 32 banks mod 64, so the two
 // 16-lane halves of a ds_read_b64 (rows k, k+1) are conflict-free without a swizzle.
-// Skipping exact zeros does not change any sum (0*x adds nothing for finite x), so results
-// are identical to the dense kernels'.
 #pragma once
 #include "dgemm_dlds.h"
+#include "band_plan.h"
 
 namespace mcml {
 
-constexpr int BD_BM = 80, BD_BN = 128, BD_BK = 32, BD_STAGES = 3;
-constexpr int BD_A_BYTES = BD_BK * BD_BM * 8;      // 20480: 20 chunks of 1 KiB
-constexpr int BD_B_BYTES = BD_BK * BD_BN * 8;      // 32768: 32 chunks
-constexpr int BD_STAGE_BYTES = BD_A_BYTES + BD_B_BYTES;
-constexpr size_t BD_LDS_BYTES = (size_t)BD_STAGES * BD_STAGE_BYTES;   // 159744
-constexpr int BD_NA = 3, BD_NB = 4, BD_PER_TILE = BD_NA + BD_NB;      // LDS-DMA pieces per wave per tile
-
 struct BandP {
     GemmP g;
-    const int* krange;     // [2*band] first K tile, [2*band+1] one past the last (units of BD_BK)
-    int nbands;
-    int mode;              // debug timing experiments: 1 no LDS-DMA, 2 no barriers, 4 no ds_reads (results meaningless)
-    unsigned long long* clocks;   // debug (nullable): workgroup 0 adds its shader-clock and 100 MHz real-time ticks
+    const BandItem* items;
+    const int* wg_ptr;     // items of workgroup w (of any column tile): [wg_ptr[w], wg_ptr[w+1])
+    int nwg;               // workgroups per column tile
+    double* part;          // partial tiles: [(slot * gn + column tile) * BD_TILE_ELEMS]
+    int mode;              // DBG kernels only -- timing experiments: 1 no LDS-DMA, 2 no barriers, 4 no ds_reads, 8 compiler-scheduled reads
+    unsigned long long* clocks;   // DBG kernels only (nullable): workgroup 0 adds its shader-clock and 100 MHz real-time ticks
 };
 
 // first / last nonzero K tile of every 80-row band of A (M x K, column-major)
@@ -106,7 +109,9 @@ __device__ __forceinline__ void bd_mfma(d4 (&acc)[5][1], const double (&a)[5], d
     for (int i = 0; i < 5; ++i) acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a[i], acc[i][0], 0, 0, 0);
 }
 
-template <class Epi>
+// DBG = true only for the timing hooks of debug_hooks.hip (bp.mode / bp.clocks); the sampler's instantiation
+// carries neither the experiment branches nor the clock reads
+template <class Epi, bool DBG>
 __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
 {
     const GemmP& p = bp.g;
@@ -115,15 +120,16 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lk = lane >> 4;
     unsigned long long t0c = 0, t0r = 0;
-    if (bp.clocks && blockIdx.x == 0 && tid == 0) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
+    if constexpr (DBG)
+        if (bp.clocks && blockIdx.x == 0 && tid == 0) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
 
-    // XCD-aware map over (band pair, column tile)
-    const int npairs = (bp.nbands + 1) >> 1;
-    const int nblk = npairs * p.gn;
+    // XCD-aware map over (workgroup of the plan, column tile): the column tiles of one run of K tiles
+    // share an XCD (they read the same pieces of A)
+    const int nblk = bp.nwg * p.gn;
     const int bid = blockIdx.x;
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
     const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int pb = nid / p.gn, bj = nid - pb * p.gn;
+    const int pw = nid / p.gn, bj = nid - pw * p.gn;
     const int n0 = bj * BD_BN;
 
     // B pieces do not depend on the band: 32 chunks, chunk c -> (kp = c >> 1, half = c & 1)
@@ -139,11 +145,12 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
     }
     const size_t stepA = (size_t)BD_BK * p.lda;
 
-    for (int pass = 0; pass < 2; ++pass) {
-        const int band = pass == 0 ? pb : bp.nbands - 1 - pb;
-        if (pass == 1 && band <= pb) break;                 // odd band count: the middle band runs once
+    const int it0 = bp.wg_ptr[pw], it1 = bp.wg_ptr[pw + 1];
+    for (int it = it0; it < it1; ++it) {
+        const BandItem item = bp.items[it];
+        const int band = item.band;
         const int m0 = band * BD_BM;
-        const int kt0 = bp.krange[2 * band], kt1 = bp.krange[2 * band + 1];
+        const int kt0 = item.kt0, kt1 = item.kt1;
 
         const double* pa[BD_NA]; int la[BD_NA];
 #pragma unroll
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
         for (int i = 0; i < 5; ++i) acc[i][0] = d4{0.0, 0.0, 0.0, 0.0};
 
         const int nk = kt1 - kt0;
-        const int mode = bp.mode;
+        const int mode = DBG ? bp.mode : 0;
         if (nk > 0 && mode == 0) {
             // per-lane LDS byte addresses of the operand reads inside stage 0
             const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)lds;
@@ -229,7 +236,8 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
                 __builtin_amdgcn_sched_barrier(0);
                 st = stn;
             }
-        } else if (nk > 0 && mode == 8) {
+        } else if (DBG && nk > 0 && mode == 8) {
+            // compiler-scheduled operand reads (the loop the hand-scheduled one replaced)
             int issued = 0;
             for (; issued < BD_STAGES - 1 && issued < nk; ++issued) issue(issued);
             wait_leave(issued - 1);
@@ -258,8 +266,8 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
                 __builtin_amdgcn_s_barrier();
                 st = st + 1; if (st >= BD_STAGES) st = 0;
             }
-        } else if (nk > 0) {
-            // timing experiments (debug hook only): the same loop with parts switched off
+        } else if (DBG && nk > 0) {
+            // timing experiments: the same loop with parts switched off (results meaningless)
             int issued = 0;
             if (!(mode & 1)) {
                 for (; issued < BD_STAGES - 1 && issued < nk; ++issued) issue(issued);
@@ -293,30 +301,73 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
                 st = st + 1; if (st >= BD_STAGES) st = 0;
             }
         }
-        epi(acc, m0, n0 + wave * 16, lane, p.M, p.N, band);
-        // the next band's first LDS-DMA may overwrite a stage another wave is still reading
+        if (item.slot < 0) {
+            epi(acc, m0, n0 + wave * 16, lane, p.M, p.N, band);
+        } else {
+            // raw accumulator tile in register order: element (wave, i, r, lane) -- each store instruction
+            // writes 512 contiguous bytes; k_band_reduce reads it back with the same thread mapping
+            double* P = bp.part + ((size_t)item.slot * p.gn + bj) * BD_TILE_ELEMS + (size_t)wave * (20 * 64) + lane;
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P[(i * 4 + r) * 64] = acc[i][0][r];
+        }
+        // the next item's first LDS-DMA may overwrite a stage another wave is still reading
         __builtin_amdgcn_s_barrier();
     }
-    if (bp.clocks && blockIdx.x == 0 && tid == 0) {
-        atomicAdd(bp.clocks, __builtin_amdgcn_s_memtime() - t0c);
-        atomicAdd(bp.clocks + 1, __builtin_amdgcn_s_memrealtime() - t0r);
-    }
+    if constexpr (DBG)
+        if (bp.clocks && blockIdx.x == 0 && tid == 0) {
+            atomicAdd(bp.clocks, __builtin_amdgcn_s_memtime() - t0c);
+            atomicAdd(bp.clocks + 1, __builtin_amdgcn_s_memrealtime() - t0r);
+        }
 }
 
+// second stage of the streamed decomposition: one workgroup of 2 waves per (split band, column tile,
+// wave pair) sums the band's pieces in K order and applies the epilogue with the GEMM kernel's own
+// register mapping
 template <class Epi>
-static inline int launch_gemm_band(hipStream_t s, int M, int N, int K, const double* A, int lda,
-                                   const double* B, int ldb, const int* krange, const Epi& epi,
+__global__ __launch_bounds__(128) void k_band_reduce(const BandRed* red, const double* part, int gn, int M, int N, Epi epi)
+{
+    const BandRed rd = red[blockIdx.x];
+    const int bj = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = blockIdx.z * 2 + (threadIdx.x >> 6);
+    d4 acc[5][1];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[i][0] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int s = rd.s0; s < rd.s1; ++s) {
+        const double* P = part + ((size_t)s * gn + bj) * BD_TILE_ELEMS + (size_t)wave * (20 * 64) + lane;
+        double v[20];
+#pragma unroll
+        for (int t = 0; t < 20; ++t) v[t] = P[t * 64];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][0][r] += v[i * 4 + r];
+    }
+    epi(acc, rd.band * BD_BM, bj * BD_BN + wave * 16, lane, M, N, rd.band);
+}
+
+template <class Epi, bool DBG = false>
+static inline int launch_gemm_band(hipStream_t s, BandPlan& plan, int N, const double* A, int lda,
+                                   const double* B, int ldb, const Epi& epi,
                                    unsigned long long* clocks = nullptr, int mode = 0)
 {
+    const int gn = (N + BD_BN - 1) / BD_BN;
+    BandPlanDev* d = nullptr;
+    MCML_TRY(plan.device_plan(gn, s, &d));
     BandP bp;
     bp.clocks = clocks;
     bp.mode = mode;
-    bp.g = GemmP{M, N, K, A, lda, B, ldb, 0, (N + BD_BN - 1) / BD_BN, 0, 0};
-    bp.krange = krange;
-    bp.nbands = (M + BD_BM - 1) / BD_BM;
-    const int npairs = (bp.nbands + 1) / 2;
-    MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&dgemm_band_kernel<Epi>), (int)BD_LDS_BYTES));
-    hipLaunchKernelGGL((dgemm_band_kernel<Epi>), dim3(npairs * bp.g.gn), dim3(512), BD_LDS_BYTES, s, bp, epi);
+    bp.g = GemmP{plan.M, N, plan.K, A, lda, B, ldb, 0, gn, 0, 0};
+    bp.items = d->items.as<BandItem>();
+    bp.wg_ptr = d->wg_ptr.as<int>();
+    bp.nwg = d->nwg;
+    bp.part = d->part.d();
+    MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&dgemm_band_kernel<Epi, DBG>), (int)BD_LDS_BYTES));
+    hipLaunchKernelGGL((dgemm_band_kernel<Epi, DBG>), dim3(d->nwg * gn), dim3(512), BD_LDS_BYTES, s, bp, epi);
+    if (d->nred > 0)
+        hipLaunchKernelGGL((k_band_reduce<Epi>), dim3(d->nred, gn, 4), dim3(128), 0, s, d->red.as<BandRed>(),
+                           d->part.d(), gn, plan.M, N, epi);
     MCML_HIP(hipGetLastError());
     return MCML_OK;
 }

@@ -80,6 +80,37 @@ __host__ __device__ __forceinline__ double glm_score_post(double var_par, int fl
     return 1.0;
 }
 
+// digamma(x), x > 0: stands where boost::math::digamma is called (mcmlmodel.h:271).  Recurrence
+// psi(x) = psi(x+1) - 1/x up to x >= 10, then ln x - 1/(2x) - sum_k B_2k/(2k x^2k), k = 1..7;
+// the same expression order as orc_digamma in oracle/mcml_oracle.c.
+__device__ __forceinline__ double glm_digamma(double x)
+{
+    if (!(x > 0)) return __builtin_nan("");
+    double r = 0.0;
+    while (x < 10.0) { r = r - 1 / x; x = x + 1; }
+    const double i2 = 1 / (x * x);
+    double t = 1.0 / 12;
+    t = 691.0 / 32760 - t * i2;
+    t = 1.0 / 132 - t * i2;
+    t = 1.0 / 240 - t * i2;
+    t = 1.0 / 252 - t * i2;
+    t = 1.0 / 120 - t * i2;
+    t = 1.0 / 12 - t * i2;
+    return r + (log(x) - 0.5 / x - t * i2);
+}
+
+// beta/logit (mcmlmodel.h:266-275): the only case where var_par enters the vector itself (the others apply it
+// after the product, glm_score_post).  Literally: the reference's second line reads the UPDATED mu(i) = p, so
+// the leading factor is p/(1+exp(p)).  Kept out of glm_score's switch so that the hot GEMM epilogues of the
+// other eleven cases do not carry the digamma loops (they cost the forward band kernel 13 VGPRs and a scratch
+// frame); callers select it with a compile-time flag (EpiForwardT<true>).
+__device__ __forceinline__ double glm_score_beta(double y, double mu, double var_par)
+{
+    const double p = exp(mu) / (exp(mu) + 1);
+    return (p / (1 + exp(p))) * var_par *
+           (log(y) - log(1 - y) - glm_digamma(p * var_par) + glm_digamma((1 - p) * var_par));
+}
+
 __device__ __forceinline__ double glm_score(double y, double mu, int flink)
 {
     switch (flink) {

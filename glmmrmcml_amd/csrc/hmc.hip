@@ -19,7 +19,6 @@
 #include "dgemm_mfma.h"
 #include "dgemm_dlds.h"
 #include "dgemm_band.h"
-#include "dgemm_band2.h"
 #include "glm.h"
 #include "reduce.h"
 #include "rng.h"
@@ -51,12 +50,17 @@ static ChainArrays chain_arrays(const HmcState& h)
 // store_mu = 0: inside a leapfrog trajectory only the score feeds the next product; the linear
 // predictor itself is read (by k_hmc_accept) after the LAST step only, so its 8 n C bytes per
 // launch are not written
-struct EpiForward {
-    double* MU; double* S; int ld; const double* xb; const double* y; int flink; int store_mu;
+template <bool BETA>
+struct EpiForwardT {
+    double* MU; double* S; int ld; const double* xb; const double* y; int flink; int store_mu; double var_par;
+    __device__ __forceinline__ double score(double yv, double mu) const {
+        if constexpr (BETA) return glm_score_beta(yv, mu, var_par);
+        else return glm_score(yv, mu, flink);
+    }
     __device__ __forceinline__ void elem(int m, int n, double accv) const {
         const double mu = xb[m] + accv;
         if (store_mu) MU[m + (size_t)n * ld] = mu;
-        S[m + (size_t)n * ld] = glm_score(y[m], mu, flink);
+        S[m + (size_t)n * ld] = score(y[m], mu);
     }
     template <int TM, int TN>
     __device__ __forceinline__ void operator()(d4 (&acc)[TM][TN], int mB, int nB, int lane, int M, int N,
@@ -74,7 +78,7 @@ struct EpiForward {
                     if (n < N) {
                         const double mu = xbi + acc[i][j][r];
                         if (store_mu) MU[m + (size_t)n * ld] = mu;
-                        S[m + (size_t)n * ld] = glm_score(yi, mu, flink);
+                        S[m + (size_t)n * ld] = score(yi, mu);
                     }
                 }
         }
@@ -421,34 +425,35 @@ static bool use_dlds()
     return v == 1;
 }
 
-// GLMMR_MCML_BAND=2: the two-workgroups-per-CU cut of the banded kernel (dgemm_band2.h)
-static int band_variant()
-{
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("GLMMR_MCML_BAND"); v = e ? atoi(e) : 1; }
-    return v;
-}
-
 // MU = xb + ZL * X ; S = score
-static int hmc_forward(Ctx& c, const double* X, int ldx, bool store_mu = true, bool chain = false)
+template <class Epi>
+static int hmc_forward_launch(Ctx& c, const double* X, int ldx, const Epi& epi)
 {
     HmcState& h = c.hmc;
-    EpiForward epi{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink, store_mu ? 1 : 0};
-    const int slot = c.prof.begin(c.stream, 0, chain);
-    int rc;
     if (c.sp.active) {
         const int gy = h.C < 256 ? h.C : 256;
-        hipLaunchKernelGGL((k_sp_forward<EpiForward>), dim3((c.n + 255) / 256, gy), dim3(256), 0, c.stream, c.n, h.C,
+        hipLaunchKernelGGL((k_sp_forward<Epi>), dim3((c.n + 255) / 256, gy), dim3(256), 0, c.stream, c.n, h.C,
                            c.sp.W, c.sp.ell_col.as<int>(), c.sp.ell_val.d(), X, ldx, epi);
-        rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
-    } else if (c.band_fwd && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
-        rc = band_variant() == 2
-                 ? launch_gemm_band2(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, c.kr_fwd.as<int>(), epi)
-                 : launch_gemm_band(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, c.kr_fwd.as<int>(), epi);
-    else if (use_dlds() && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
-        rc = launch_gemm_dlds(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
+        return (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
+    }
+    if (c.band_fwd && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
+        return launch_gemm_band(c.stream, c.plan_fwd, h.C, c.ZL.d(), c.ZL.ld, X, ldx, epi);
+    if (use_dlds() && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
+        return launch_gemm_dlds(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
+    return launch_gemm<false>(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
+}
+
+static int hmc_forward(Ctx& c, const double* X, int ldx, double var_par, bool store_mu = true, bool chain = false)
+{
+    HmcState& h = c.hmc;
+    const int slot = c.prof.begin(c.stream, 0, chain);
+    int rc;
+    if (c.flink == 12)      // beta/logit: the digamma score is its own instantiation (glm.h)
+        rc = hmc_forward_launch(c, X, ldx, EpiForwardT<true>{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink,
+                                                             store_mu ? 1 : 0, var_par});
     else
-        rc = launch_gemm<false>(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
+        rc = hmc_forward_launch(c, X, ldx, EpiForwardT<false>{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink,
+                                                              store_mu ? 1 : 0, var_par});
     c.prof.end(c.stream, slot);
     return rc;
 }
@@ -473,9 +478,7 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
                            h.S.d(), h.S.ld, epi);
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
     } else if (c.band_bwd && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
-        rc = band_variant() == 2
-                 ? launch_gemm_band2(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, c.kr_bwd.as<int>(), epi)
-                 : launch_gemm_band(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, c.kr_bwd.as<int>(), epi);
+        rc = launch_gemm_band(c.stream, c.plan_bwd, h.C, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
     else if (use_dlds() && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
         rc = launch_gemm_dlds(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
     else
@@ -489,7 +492,7 @@ static int hmc_eval_state(Ctx& c, double var_par)
 {
     HmcState& h = c.hmc;
     ChainArrays ca = chain_arrays(h);
-    MCML_TRY(hmc_forward(c, h.V.d(), h.V.ld));
+    MCML_TRY(hmc_forward(c, h.V.d(), h.V.ld, var_par));
     hipLaunchKernelGGL(k_hmc_lp0, dim3(h.C), dim3(256), 0, c.stream, h.MU.d(), h.MU.ld, c.n, h.V.d(), h.V.ld, c.Q,
                        c.y.d(), var_par, c.flink, ca.lpcur);
     MCML_HIP(hipGetLastError());
@@ -583,7 +586,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         }
         MCML_REQUIRE(maxs >= 1 && maxs <= o->max_steps, "hmc: step count %d out of range", maxs);
         for (int s = 0; s < maxs; ++s) {
-            MCML_TRY(hmc_forward(c, h.UP.d(), h.UP.ld, s == maxs - 1, s > 0));
+            MCML_TRY(hmc_forward(c, h.UP.d(), h.UP.ld, var_par, s == maxs - 1, s > 0));
             MCML_TRY(hmc_backward(c, h.UP.d(), h.GRADP.d(), s, var_par, 1, true));
         }
         c.prof.unchain();

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_la_logdet(const double* A, int lda, int
 
 // mcnr_b's per-observation pieces (mcmloptim.h:248-266): resid, Wu = W detadmu resid, score(xb + Zv)
 __global__ void k_la_nr_obs(const double* y, const double* xb, const double* zlv, const double* zv, const double* W,
-                            int n, int flink, int link_code, double* resid, double* Wu, double* score)
+                            int n, int flink, int link_code, double var_par, double* resid, double* Wu, double* score)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -124,7 +124,7 @@ __global__ void k_la_nr_obs(const double* y, const double* xb, const double* zlv
     const double r = y[i] - glm_mod_inv(eta, link_code);
     resid[i] = r;
     Wu[i] = W[i] * glm_detadmu(eta, link_code) * r;
-    score[i] = glm_score(y[i], xb[i] + zv[i], flink);
+    score[i] = flink == 12 ? glm_score_beta(y[i], xb[i] + zv[i], var_par) : glm_score(y[i], xb[i] + zv[i], flink);
 }
 
 __global__ void k_la_axpy(double* y, const double* x, double a, int n)
@@ -430,7 +430,7 @@ struct LaFit {
         MCML_TRY(zl_times_v(tmpn.d()));                           // zd = ZL v
         MCML_TRY(z_times_v(zv.d()));                              // Z v (log_grad with usezl = false)
         hipLaunchKernelGGL(k_la_nr_obs, dim3((n + 255) / 256), dim3(256), 0, c.stream, c.y.d(), c.xb.d(), tmpn.d(), zv.d(),
-                           W.d(), n, flink, link_code, tmpn2.d(), tmpn3.d(), tmpn.d());
+                           W.d(), n, flink, link_code, var_par, tmpn2.d(), tmpn3.d(), tmpn.d());
         MCML_HIP(hipGetLastError());
         // tmpn2 = resid, tmpn3 = Wu, tmpn = score(xb + Z v)
         hipLaunchKernelGGL(k_la_xtwx, dim3(P * P + P), dim3(256), 0, c.stream, c.X.d(), c.X.ld, n, P, W.d(), tmpn3.d(), small.d());

@@ -17,21 +17,6 @@
 
 namespace mcml {
 
-// ------------------------------------------------------------------ reduce hook
-// sums `n` host doubles over all ranks (identity when single-process)
-int allreduce_host(Ctx& c, double* vals, int n)
-{
-    if (!c.reduce || c.world <= 1) return MCML_OK;
-    MCML_TRY(c.reduce_buf.ensure(sizeof(double) * (size_t)n));
-    MCML_HIP(hipMemcpyAsync(c.reduce_buf.p, vals, sizeof(double) * n, hipMemcpyHostToDevice, c.stream));
-    MCML_HIP(hipStreamSynchronize(c.stream));
-    int rc = c.reduce(c.reduce_user, c.reduce_buf.d(), n);
-    if (rc) { set_error("reduce hook failed (%d)", rc); return MCML_EINVAL; }
-    MCML_HIP(hipMemcpyAsync(vals, c.reduce_buf.p, sizeof(double) * n, hipMemcpyDeviceToHost, c.stream));
-    MCML_HIP(hipStreamSynchronize(c.stream));
-    return MCML_OK;
-}
-
 // ------------------------------------------------------------------ setup
 int model_setup(Ctx& c, const double* Z, const double* X, const double* y)
 {
@@ -248,23 +233,22 @@ int model_update_L(Ctx& c)
     c.band_fwd = c.band_bwd = false;
     const char* env = getenv("GLMMR_MCML_GEMM");
     if (!(env && (!strcmp(env, "reg") || !strcmp(env, "dlds")))) {
-        auto ranges = [&](const DevMat& A, int M, int K, DevBuf& kr, bool& use, long& ntiles) -> int {
+        auto ranges = [&](const DevMat& A, int M, int K, BandPlan& plan, bool& use, long& ntiles) -> int {
             const int nb = (M + BD_BM - 1) / BD_BM;
-            MCML_TRY(kr.ensure(sizeof(int) * 2 * (size_t)nb));
-            hipLaunchKernelGGL(k_band_ranges, dim3(nb), dim3(256), 0, c.stream, A.d(), A.ld, M, K, kr.as<int>());
+            MCML_TRY(c.kr_scratch.ensure(sizeof(int) * 2 * (size_t)nb));
+            hipLaunchKernelGGL(k_band_ranges, dim3(nb), dim3(256), 0, c.stream, A.d(), A.ld, M, K, c.kr_scratch.as<int>());
             MCML_HIP(hipGetLastError());
             std::vector<int> h(2 * (size_t)nb);
-            MCML_HIP(hipMemcpyAsync(h.data(), kr.p, sizeof(int) * h.size(), hipMemcpyDeviceToHost, c.stream));
+            MCML_HIP(hipMemcpyAsync(h.data(), c.kr_scratch.p, sizeof(int) * h.size(), hipMemcpyDeviceToHost, c.stream));
             MCML_HIP(hipStreamSynchronize(c.stream));
-            long tiles = 0;
-            for (int b = 0; b < nb; ++b) tiles += h[2 * b + 1] - h[2 * b];
+            plan.reset(M, K, h);               // the per-chain-count decompositions are rebuilt on first use
             const long dense = (long)nb * ((K + BD_BK - 1) / BD_BK);
-            use = (env && !strcmp(env, "band")) || tiles * 5 <= dense * 4;
-            ntiles = tiles;
+            use = (env && !strcmp(env, "band")) || plan.tiles * 5 <= dense * 4;
+            ntiles = plan.tiles;
             return MCML_OK;
         };
-        MCML_TRY(ranges(c.ZL, c.n, c.Q, c.kr_fwd, c.band_fwd, c.band_fwd_tiles));
-        MCML_TRY(ranges(c.ZLT, c.Q, c.n, c.kr_bwd, c.band_bwd, c.band_bwd_tiles));
+        MCML_TRY(ranges(c.ZL, c.n, c.Q, c.plan_fwd, c.band_fwd, c.band_fwd_tiles));
+        MCML_TRY(ranges(c.ZLT, c.Q, c.n, c.plan_bwd, c.band_bwd, c.band_bwd_tiles));
     }
     return MCML_OK;
 }
@@ -390,11 +374,7 @@ int model_mcnr_stats(Ctx& c, double var_par, double* stats)
     hipLaunchKernelGGL(k_mcnr_fin, dim3(1), dim3(256), 0, c.stream, c.X.d(), c.X.ld, n, P, wsum, wusum, sig, m,
                        c.reduce_buf.d());
     MCML_HIP(hipGetLastError());
-    if (c.reduce && c.world > 1) {
-        MCML_HIP(hipStreamSynchronize(c.stream));
-        int rc = c.reduce(c.reduce_user, c.reduce_buf.d(), ns);   // RCCL all-reduce of the statistics
-        if (rc) { set_error("reduce hook failed (%d)", rc); return MCML_EINVAL; }
-    }
+    MCML_TRY(allreduce_dev(c, c.reduce_buf.d(), ns));              // RCCL all-reduce of the statistics (comm.hip)
     MCML_HIP(hipMemcpyAsync(stats, c.reduce_buf.p, sizeof(double) * ns, hipMemcpyDeviceToHost, c.stream));
     MCML_HIP(hipStreamSynchronize(c.stream));
     return MCML_OK;

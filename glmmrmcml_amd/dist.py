@@ -60,3 +60,17 @@ def make_reduce_hook(group=None):
             print("glmmrmcml_amd.dist: reduce hook failed:", e, flush=True)
             return 1
     return hook
+
+
+def init_native_rccl(ctx, rank, world, group=None, device=None):
+    """give `ctx` its own RCCL communicator (csrc/comm.hip): rank 0 makes the id, torch.distributed only carries
+    the 128 bytes to the other ranks; afterwards the library all-reduces on its own stream with no callback."""
+    import torch
+    import torch.distributed as dist
+    from . import api
+    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    t = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        t.copy_(torch.tensor(list(api.rccl_unique_id()), dtype=torch.uint8))
+    dist.broadcast(t, src=0, group=group)
+    ctx.comm_init_rccl(bytes(t.cpu().tolist()), rank, world)

@@ -30,34 +30,47 @@ _Z975 = 1.959963984540054                                     # qnorm(1 - 0.05 /
 _VAR_FAMILIES = ("gaussian", "Gamma", "beta")
 
 
+_FLINK = {"poissonlog": 1, "poissonidentity": 2, "binomiallogit": 3, "binomiallog": 4, "binomialidentity": 5,
+          "binomialprobit": 6, "gaussianidentity": 7, "gaussianlog": 8, "gammalog": 9, "gammainverse": 10,
+          "gammaidentity": 11, "betalogit": 12}                # mcmlmodel.h:74-87
+
+
 def _dhdmu(xb, family, link):
-    """glmmrBase gen_dhdmu (restated from its use at R6ModelExtMCML.R:558 and maths::dhdmu's call sites)"""
+    """glmmrBase `gen_dhdmu` (R6ModelExtMCML.R:558,815) is the Rcpp export of `glmmr::maths::dhdmu`, the function
+    mcmlmodel.h:122 calls for the MCNR weights: ONE table, the one csrc/glm.h::glm_dhdmu and
+    oracle/mcml_oracle.c::orc_dhdmu restate.  glmmrBase is not in the image, so the table is INFERRED (parity
+    unpinned): it is written the way glmmrBase 0.2.x's maths.h is remembered to write it -- cases 3, 4, 5 and 12
+    take p from the LOGISTIC inverse link whatever the link, case 8 is exp(-eta) -- and not re-derived from GLM theory
+    (for binomial/log and binomial/identity the textbook working weights differ).  tests/test_model_caller.py
+    checks this function against the oracle's for all 12 cases."""
     xb = np.asarray(xb, float)
     key = family.lower() + link
-    if key == "poissonlog":
-        return np.exp(-xb)
-    if key == "poissonidentity":
+    if key not in _FLINK:
+        raise ValueError("unknown family/link %s/%s" % (family, link))
+    fl = _FLINK[key]
+    if fl == 1:
+        return np.exp(-1.0 * xb)
+    if fl == 2:
         return np.exp(xb)
-    if key == "binomiallogit":
-        return (1 + np.exp(xb)) ** 2 / np.exp(xb)
-    if key == "binomiallog":
-        return (1 - np.exp(xb)) / np.exp(xb)
-    if key == "binomialidentity":
-        return 1 / (xb * (1 - xb))
-    if key == "binomialprobit":
-        from math import erf, sqrt, pi
-        p = np.array([0.5 * (1 + erf(v / sqrt(2))) for v in xb])
-        d = np.exp(-0.5 * xb ** 2) / sqrt(2 * pi)
-        return p * (1 - p) / d
-    if key in ("gaussianidentity", "gaussianlog", "gammalog"):
+    if fl in (3, 4, 5, 12):
+        p = np.exp(xb) / (1 + np.exp(xb))
+        if fl == 4:
+            return (1.0 - p) / p
+        if fl == 5:
+            return p * (1.0 - p)
+        return 1 / (p * (1.0 - p))
+    if fl == 6:
+        from math import erfc
+        p = np.array([0.5 * erfc(-v * 0.70710678118654752440) for v in np.atleast_1d(xb)]).reshape(xb.shape)
+        d = np.exp(-0.5 * xb * xb) * 0.39894228040143267794
+        return (p * (1 - p)) / d
+    if fl in (7, 9):
         return np.ones_like(xb)
-    if key == "gammainverse":
-        return 1 / xb ** 2
-    if key == "gammaidentity":
-        return xb ** 2
-    if key == "betalogit":
-        return (1 + np.exp(xb)) ** 2 / np.exp(xb)
-    raise ValueError("unknown family/link %s/%s" % (family, link))
+    if fl == 8:
+        return 1 / np.exp(xb)
+    if fl == 10:
+        return 1 / (xb * xb)
+    return xb * xb                                             # 11
 
 
 class McmlFit(dict):

@@ -71,6 +71,19 @@ int glmmr_mcml_ctx_create(const glmmr_mcml_problem* prob, const glmmr_mcml_dev_o
                           glmmr_mcml_ctx** out);
 int glmmr_mcml_ctx_destroy(glmmr_mcml_ctx* ctx);
 
+/* Native multi-GPU exchange (no reference counterpart: the reference is one process, src/Makevars:14-15;
+ * north-star row 8(e)).  One process per GPU; rank 0 makes an id, the host program hands the 128 bytes to the
+ * other ranks by whatever transport it has (MPI, a file, R's parallel sockets, torch.distributed), every rank
+ * calls comm_init_rccl on its context.  From then on every statistic the path exchanges -- P*P+P+2 doubles per
+ * MCNR step, (sum, count) per objective evaluation -- is ONE ncclAllReduce(sum, f64) on the context's stream
+ * (RCCL over xGMI), with no host synchronisation in front of it; `reduce` above is ignored.  librccl.so is
+ * loaded on first use. */
+#define GLMMR_MCML_RCCL_ID_BYTES 128
+int glmmr_mcml_rccl_unique_id(unsigned char* id128);
+int glmmr_mcml_ctx_comm_init_rccl(glmmr_mcml_ctx* ctx, const unsigned char* id128, int rank, int world);
+/* collectives issued so far, doubles summed, 1 if the native communicator is in use (all nullable) */
+int glmmr_mcml_ctx_comm_stats(glmmr_mcml_ctx* ctx, long long* calls, long long* doubles, int* native);
+
 /* samples u (Q x ncols, this rank's columns).  niter = columns the beta-step
  * reads (mcmlmodel.h:73,296); the theta-step reads all ncols (mcmldmatrix.h:24). */
 int glmmr_mcml_set_u(glmmr_mcml_ctx* ctx, const double* u, int Q, int ncols, int niter);

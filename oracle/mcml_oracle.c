@@ -668,6 +668,28 @@ double orc_log_prob(int n, int Q, const double *xb, const double *ZL, const doub
     return ll + lp;
 }
 
+/* digamma(x), x > 0 -- stands where boost::math::digamma is called
+ * (mcmlmodel.h:271; boost is not in the image).  Published algorithm, the build's own
+ * statement of it: psi(x) = psi(x+1) - 1/x up to x >= 10, then the asymptotic series
+ * ln x - 1/(2x) - sum_k B_2k / (2k x^2k), k = 1..7 (next term < 5e-17 at x = 10).
+ * Same expression order as glm_digamma in glmmrmcml_amd/csrc/glm.h.  KAT: scipy.special.digamma
+ * (tests/test_oracle_kat.py). */
+double orc_digamma(double x)
+{
+    if (!(x > 0)) return 0.0 / 0.0;
+    double r = 0.0;
+    while (x < 10.0) { r = r - 1 / x; x = x + 1; }
+    const double i2 = 1 / (x * x);
+    double t = 1.0 / 12;                       /* B14/14 */
+    t = 691.0 / 32760 - t * i2;                /* B12/12 */
+    t = 1.0 / 132 - t * i2;                    /* B10/10 */
+    t = 1.0 / 240 - t * i2;                    /* B8/8   */
+    t = 1.0 / 252 - t * i2;                    /* B6/6   */
+    t = 1.0 / 120 - t * i2;                    /* B4/4   */
+    t = 1.0 / 12 - t * i2;                     /* B2/2   */
+    return r + (log(x) - 0.5 / x - t * i2);
+}
+
 /* the score s(y,mu) applied before ZL' (mcmlmodel.h:169-276) and the scalar
  * applied after it */
 static double score(double y, double mu, double var_par, int flink, double *post)
@@ -687,7 +709,12 @@ static double score(double y, double mu, double var_par, int flink, double *post
     case 9: *post = var_par; return y * exp(-1.0 * mu) - 1;
     case 10: *post = var_par; return (1 / mu) - y;
     case 11: *post = var_par; { double im = 1 / mu; return y * im * im - im; }
-    case 12: return 0.0 / 0.0; /* needs boost digamma: not built */
+    case 12: {   /* mcmlmodel.h:266-275, literally: the second line reads the UPDATED mu(i) (= p), so the
+                  * factor is p/(1+exp(p)), not p(1-p) */
+        double p = exp(mu) / (exp(mu) + 1);
+        return (p / (1 + exp(p))) * var_par *
+               (log(y) - log(1 - y) - orc_digamma(p * var_par) + orc_digamma((1 - p) * var_par));
+    }
     }
     return 0;
 }

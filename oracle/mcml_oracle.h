@@ -45,6 +45,7 @@ double orc_logpdf(double y, double mu, double var_par, int flink);
 double orc_mod_inv(double eta, int link_code);
 double orc_dhdmu(double eta, int flink);
 double orc_detadmu(double eta, int link_code);
+double orc_digamma(double x);
 
 /* ---- covariance / MVN log-likelihood (mcmldmatrix.h + glmmrBase restated) ---- */
 int orc_cov_npar(const int32_t *cov, int rows);

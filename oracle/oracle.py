@@ -73,6 +73,8 @@ def lib():
         for f in (L.orc_mod_inv, L.orc_dhdmu, L.orc_detadmu):
             f.restype = C.c_double
             f.argtypes = [C.c_double, C.c_int]
+        L.orc_digamma.restype = C.c_double
+        L.orc_digamma.argtypes = [C.c_double]
         L.orc_log_prob.restype = C.c_double
         L.orc_log_prob.argtypes = [C.c_int, C.c_int, c_dp, c_dp, c_dp, C.c_double, C.c_int, c_dp]
         L.orc_log_grad.argtypes = [C.c_int, C.c_int, c_dp, c_dp, c_dp, C.c_double, C.c_int, c_dp, c_dp]
@@ -183,6 +185,15 @@ def mvn_ll(cov, data, eff_range, gamma, u, per_column_refactor=False):
 
 
 # ---- model ------------------------------------------------------------------
+def digamma(x):
+    return lib().orc_digamma(float(x))
+
+
+def dhdmu(eta, fl):
+    """glmmrBase maths::dhdmu as restated in mcml_oracle.c (the ONE table: csrc/glm.h and model.py follow it)"""
+    return np.array([lib().orc_dhdmu(float(e), int(fl)) for e in np.atleast_1d(eta)])
+
+
 def log_prob(xb, ZL, y, var_par, fl, v):
     xb = _f(xb); ZL = _f(ZL); y = _f(y); v = _f(v)
     n, Q = ZL.shape

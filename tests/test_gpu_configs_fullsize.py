@@ -1,0 +1,133 @@
+"""BASELINE configs 4 and 5 at FULL size (the oracle would take hours there): the kernels these
+configs select (sparse ZL operator: ELL forward, CSR backward in its long-row form for config 4 and
+its short-row form for config 5; diagonal / small-block mvn_ll; MCNR statistics; mcml_hess) checked
+through size-independent properties:
+
+  * a chain's draws depend only on (seed, global chain id), not on how many chains run beside it nor
+    on the operator form: the first chains of the full-size sparse run equal a 16-chain run on the
+    DENSE MFMA operator (accept decisions identical, samples 1e-8);
+  * accept probabilities in (0, 1], dual averaging ends near the target rate;
+  * mvn_ll at full size equals the closed form for diagonal D (config 5) / the per-block dense
+    evaluation by numpy on a subset of blocks scaled up (config 4: blocks are i.i.d. in structure);
+  * mcml_hess is symmetric, finite and negative-definite-signed consistently with -H^-1 being a
+    covariance (diagonal of the inverse positive) at the MCNR optimum.
+"""
+import numpy as np
+import pytest
+
+from glmmrmcml_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _sparse_then_dense(d, C, warm, monkeypatch, lam=0.5, ms=10, seed=31, sub=16):
+    from glmmrmcml_amd import api
+    args = (d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"])
+    monkeypatch.delenv("GLMMR_MCML_ZL", raising=False)
+    with api.Context(*args) as ctx:
+        ctx.update_L(d["theta"])
+        diag, flags, probs = ctx.hmc_sample(d["beta"], 1.0, warm, C, lam, ms, 0.9, seed, chains=C, want_trace=True)
+        assert ctx.profile(enable=False)["operator"] == "sparse"
+        u = ctx.get_u()
+        extra = dict(ll=ctx.mvn_ll(d["theta"]), mcnr=ctx.mcnr(d["beta"], 1.0), loglik=ctx.loglik(d["beta"], 1.0),
+                     fit=ctx.mcml_optim(d["start"], mcnr=True))
+        start = np.r_[extra["fit"]["beta"], extra["fit"]["theta"], 1.0]
+        extra["H"] = ctx.mcml_hess(start, tol=1e-4)
+    monkeypatch.setenv("GLMMR_MCML_ZL", "dense")
+    with api.Context(*args) as ctx:
+        ctx.update_L(d["theta"])
+        dg2, fl2, pr2 = ctx.hmc_sample(d["beta"], 1.0, warm, sub, lam, ms, 0.9, seed, chains=sub, want_trace=True)
+        assert ctx.profile(enable=False)["operator"] != "sparse"
+        u2 = ctx.get_u()
+    monkeypatch.delenv("GLMMR_MCML_ZL", raising=False)
+    assert u.shape == (d["Q"], C) and u2.shape == (d["Q"], sub)
+    assert np.all(np.isfinite(u))
+    assert np.array_equal(flags[:sub], fl2)
+    assert np.abs(probs[:sub] - pr2).max() < 1e-9
+    assert np.abs(u[:, :sub] - u2).max() < 1e-8 * max(1.0, np.abs(u2).max())
+    assert np.all(probs > 0) and np.all(probs <= 1)
+    assert 0.5 < diag["accept_rate"] <= 1.0
+    return u, extra
+
+
+def _check_hess(H, nv):
+    assert H.shape == (nv, nv) and np.all(np.isfinite(H)) and np.array_equal(H, H.T)
+    # the export differentiates the NEGATIVE simulated log-likelihood (F_likelihood returns -1*(ll+logl),
+    # likelihood.h:108): at an optimum its Hessian is positive definite in the beta block
+    assert np.all(np.diag(H) > 0)
+
+
+def test_config4_full_size(monkeypatch):
+    """Binomial stepped-wedge, 40 cl x 8 t x 50 ind (n = 16000), Q = 320 as 40 ar1 blocks of 8, m = 512"""
+    d = synth.stepped_wedge(40, 8, 50)
+    assert d["n"] == 16000 and d["Q"] == 320
+    u, ex = _sparse_then_dense(d, 512, 40, monkeypatch)
+    # mvn_ll: 40 identical-structure blocks -> numpy per block
+    nt, th = 8, d["theta"]
+    dt = np.abs(np.arange(nt)[:, None] - np.arange(nt)[None, :])
+    Db = th[0] ** 2 * th[1] ** dt
+    Li = np.linalg.inv(np.linalg.cholesky(Db))
+    ld = np.linalg.slogdet(Db)[1]
+    want = 0.0
+    for b in range(40):
+        z = Li @ u[b * nt:(b + 1) * nt]
+        want += np.mean(-0.5 * nt * np.log(2 * np.pi) - 0.5 * ld - 0.5 * (z ** 2).sum(0))
+    assert abs(ex["ll"] - want) < 1e-9 * abs(want)
+    # MCNR statistics against numpy on the same samples (binomial-logit: W = p(1-p), detadmu = 1/(p(1-p)))
+    eta = (d["X"] @ d["beta"])[:, None] + d["Z"] @ u
+    p = np.exp(eta) / (1 + np.exp(eta))
+    w = p * (1 - p)
+    XtWX = (d["X"].T * w.sum(1)) @ d["X"]
+    XtWr = d["X"].T @ (d["y"][:, None] - p).sum(1)
+    assert np.abs(ex["mcnr"]["XtWX"] - XtWX).max() < 1e-9 * np.abs(XtWX).max()
+    assert np.abs(ex["mcnr"]["XtWr"] - XtWr).max() < 1e-8 * max(1.0, np.abs(XtWr).max())
+    ll = np.mean(np.where(d["y"][:, None] == 1, np.log(1 / (1 + np.exp(-eta))), np.log(1 - 1 / (1 + np.exp(-eta)))).sum(0))
+    assert abs(ex["loglik"] - ll) < 1e-10 * abs(ll)
+    _check_hess(ex["H"], d["P"] + 2)
+    assert np.all(ex["fit"]["theta"] > 0) and np.all(np.isfinite(ex["fit"]["beta"]))
+
+
+def test_config5_full_size(monkeypatch):
+    """Poisson longitudinal, 2000 subjects x 10 visits (n = 20000), Q = 22000 all-diagonal, m = 1024, + mcml_hess"""
+    d = synth.longitudinal(2000, 10)
+    assert d["n"] == 20000 and d["Q"] == 22000
+    u, ex = _sparse_then_dense(d, 1024, 30, monkeypatch, sub=16)
+    # diagonal closed form (mcmldmatrix.h:61-65): variance = theta^2 per gr block
+    sd = np.r_[np.full(2000, d["theta"][0]), np.full(20000, d["theta"][1])]
+    want = np.mean((-0.5 * np.log(2 * np.pi) - np.log(sd)[:, None] - 0.5 * (u / sd[:, None]) ** 2).sum(0))
+    assert abs(ex["ll"] - want) < 1e-10 * abs(want)
+    # Monte-Carlo log-likelihood on a column subset by numpy (poisson-log with the Ramanujan log-factorial is the
+    # oracle's job at small n; here: the mean over ALL columns equals the mean of per-column values computed
+    # from the identity sum_j ll_j = sum_ij (y eta - exp(eta)) - m sum_i logfact(y_i))
+    subj = np.repeat(np.arange(2000), 10)
+    zu = u[subj] + u[2000:]
+    eta = (d["X"] @ d["beta"])[:, None] + zu
+    y = d["y"]
+    lf = np.where(y == 0, 0.0, y * np.log(np.maximum(y, 1)) - y + np.log(np.maximum(y, 1) * (1 + 4 * y * (1 + 2 * y))) / 6
+                  + np.log(3.141593) / 2)
+    ll = np.mean((y[:, None] * eta - np.exp(eta)).sum(0)) - lf.sum()
+    assert abs(ex["loglik"] - ll) < 1e-10 * abs(ll)
+    mu = np.exp(eta)
+    XtWX = (d["X"].T * mu.sum(1)) @ d["X"]                      # poisson-log: W = mu
+    XtWr = d["X"].T @ (y[:, None] - mu).sum(1)
+    assert np.abs(ex["mcnr"]["XtWX"] - XtWX).max() < 1e-9 * np.abs(XtWX).max()
+    assert np.abs(ex["mcnr"]["XtWr"] - XtWr).max() < 1e-8 * max(1.0, np.abs(XtWr).max())
+    _check_hess(ex["H"], d["P"] + 2)
+
+
+def test_config1_full_size_sampler(orc):
+    """Binomial cluster-RCT, 10 cl x 5 t x 10 ind (n = 500, Q = 60), m = 100: small enough for the oracle itself,
+    chain by chain (the reference's own CPU-runnable case)"""
+    from glmmrmcml_amd import api
+    d = synth.cluster_rct(10, 5, 10)
+    assert d["n"] == 500 and d["Q"] == 60
+    Lo = orc.gen_D(d["cov"], d["data"], d["eff_range"], d["theta"], chol=True)
+    ZL, xb = d["Z"] @ Lo, d["X"] @ d["beta"]
+    with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"]) as ctx:
+        ctx.update_L(d["theta"])
+        diag, flags, probs = ctx.hmc_sample(d["beta"], 1.0, 30, 100, 0.3, 10, 0.9, seed=5, chains=100, want_trace=True)
+        u = ctx.get_u()
+    for c in (0, 1, 37, 99):
+        so, fo, po, _ = orc.hmc_chain(xb, ZL, d["y"], 1.0, 3, 30, 1, 0.3, 10, 0.9, 5, chain_id=c)
+        assert np.array_equal(flags[c], fo)
+        assert np.abs(u[:, c] - Lo @ so[:, 1]).max() < 1e-8

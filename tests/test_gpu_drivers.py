@@ -137,3 +137,36 @@ def test_mcml_full_iteration_by_iteration(orc, chains, mcnr):
     assert np.abs(got["beta"] - beta).max() < 2e-6 * max(1.0, np.abs(beta).max())
     assert np.abs(got["theta"] - theta).max() < 2e-6
     assert np.abs(got["u"] - u).max() < 1e-6
+
+
+def test_simlik_sparse_and_hess_sparse_vs_oracle(orc):
+    """mcml_simlik_sparse / mcml_hess_sparse (src/mcml_optim.cpp:210-239,313-337): same quantities as the dense
+    exports computed through the (Ap, Ai) entry points, vs the oracle drivers (defect D1 -- the reference's sparse
+    loglik solves column 0 only -- is fixed on both sides: all columns)"""
+    from glmmrmcml_amd import api
+    from oracle import drivers
+    from scipy import sparse
+    d = synth.stepped_wedge(ncl=7, nt=4, nind=5, seed=11)
+    u = _u(orc, d, 28, seed=6)
+    D = sparse.csc_matrix(np.triu(orc.gen_D(d["cov"], d["data"], d["eff_range"], d["theta"])))
+    mod = drivers.Model(*_args(d), d["family"], d["link"])
+    got = api.mcml_simlik_sparse(d["cov"], d["data"], d["eff_range"], D.indptr, D.indices, d["Z"], d["X"], d["y"], u,
+                                 d["family"], d["link"], d["start"])
+    want = drivers.mcml_simlik(mod, u, d["start"])
+    assert np.abs(got["beta"] - want["beta"]).max() < 1e-5 * max(1.0, np.abs(want["beta"]).max())
+    assert np.abs(got["theta"] - want["theta"]).max() < 1e-5
+    F = mod.F_obj(u, 28, 0.0)
+    fg, fw = F(np.r_[got["beta"], got["theta"]]), F(np.r_[want["beta"], want["theta"]])
+    assert abs(fg - fw) < 1e-6 * abs(fw)
+    start = np.r_[want["beta"], want["theta"], 1.0]
+    H = api.mcml_hess_sparse(d["cov"], d["data"], d["eff_range"], D.indptr, D.indices, d["Z"], d["X"], d["y"], u,
+                             d["family"], d["link"], start, tol=1e-4)
+    Ho = drivers.mcml_hess(mod, u, start, tol=1e-4)
+    assert np.abs(H - Ho).max() < 1e-4 * np.abs(Ho).max()
+    assert np.array_equal(H, H.T)
+    # and the sparse entry points refuse a pattern outside the declared blocks
+    from glmmrmcml_amd import _lib
+    bad = D.indices.copy(); bad[-1] = 0
+    with pytest.raises(_lib.McmlError):
+        api.mcml_simlik_sparse(d["cov"], d["data"], d["eff_range"], D.indptr, bad, d["Z"], d["X"], d["y"], u,
+                               d["family"], d["link"], d["start"])

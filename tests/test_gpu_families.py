@@ -1,5 +1,6 @@
-"""Every family / link case of the reference's switch (moremaths.h:26-102, mcmlmodel.h:169-276: flink 1..11; 12 =
-beta-logit for the log-pdf only, its score needs boost's digamma) through the GPU path vs the oracle: log_prob,
+"""Every family / link case of the reference's switch (moremaths.h:26-102, mcmlmodel.h:169-276: flink 1..12; the
+beta-logit score calls boost::math::digamma, restated as recurrence + asymptotic series identically in
+oracle/mcml_oracle.c and csrc/glm.h) through the GPU path vs the oracle: log_prob,
 log_grad, the Monte-Carlo log-likelihood, the MCNR statistics and one HMC chain's accept decisions.
 Tolerance 1e-10 relative (f64, different summation order)."""
 import numpy as np
@@ -50,7 +51,8 @@ def _design(family, link, seed=5):
 
 CASES = [("poisson", "log", 1.0), ("poisson", "identity", 1.0), ("binomial", "logit", 1.0), ("binomial", "log", 1.0),
          ("binomial", "identity", 1.0), ("binomial", "probit", 1.0), ("gaussian", "identity", 0.7),
-         ("gaussian", "log", 0.6), ("gamma", "log", 2.0), ("gamma", "inverse", 2.0), ("gamma", "identity", 2.0)]
+         ("gaussian", "log", 0.6), ("gamma", "log", 2.0), ("gamma", "inverse", 2.0), ("gamma", "identity", 2.0),
+         ("beta", "logit", 4.0)]
 
 
 @pytest.mark.parametrize("family,link,vp", CASES)
@@ -80,7 +82,7 @@ def test_log_prob_grad_loglik_mcnr(orc, family, link, vp):
         assert r["sigma"] == pytest.approx(ro["sigma"], rel=1e-9)
 
 
-@pytest.mark.parametrize("family,link,vp", [CASES[1], CASES[3], CASES[5], CASES[7], CASES[8], CASES[9]])
+@pytest.mark.parametrize("family,link,vp", [CASES[1], CASES[3], CASES[5], CASES[7], CASES[8], CASES[9], CASES[11]])
 def test_hmc_chain_decisions(orc, family, link, vp):
     d = _design(family, link, seed=9)
     fl = orc.flink(family, link)
@@ -101,8 +103,8 @@ def test_hmc_chain_decisions(orc, family, link, vp):
         assert np.abs(u[:, c * 3:(c + 1) * 3] - uo).max() < 1e-8 * max(1.0, np.abs(uo).max())
 
 
-def test_beta_family_logpdf_only(orc):
-    """flink 12: the log-pdf (lgamma form, moremaths.h:95-99) is built; the sampler's score is not (boost digamma)"""
+def test_beta_family_logpdf(orc):
+    """flink 12: the log-pdf (lgamma form, moremaths.h:95-99) at a second dispersion value"""
     d = _design("beta", "logit")
     fl = orc.flink("beta", "logit")
     assert fl == 12

@@ -41,7 +41,9 @@ def _setup(orc, d, api):
 CASES = [(synth.geospatial, dict(n=96), 0.9), (synth.geospatial, dict(n=333), 1.0),
          (synth.cluster_rct, dict(ncl=6, nt=4, nind=5), 1.0),
          (synth.cluster_rct, dict(ncl=6, nt=4, nind=5, family="poisson"), 1.0),
-         (synth.stepped_wedge, dict(ncl=9, nt=4, nind=5), 1.0)]
+         (synth.stepped_wedge, dict(ncl=9, nt=4, nind=5), 1.0),
+         # nnz(ZL) / Q = 75 >= 24: the wave-per-random-effect backward kernel config 4 selects at full size
+         (synth.stepped_wedge, dict(ncl=6, nt=4, nind=30), 1.0)]
 
 
 @pytest.mark.parametrize("gen,kw,vp", CASES)
@@ -129,7 +131,8 @@ def test_many_chains_recover_gaussian_posterior(orc):
 def test_sparse_and_dense_zl_operators_agree(monkeypatch):
     """configs 1/4/5: the ELL/CSR ZL operator and the dense MFMA GEMMs are the same sampler"""
     from glmmrmcml_amd import api
-    for gen, kw in ((synth.stepped_wedge, dict(ncl=9, nt=6, nind=12)), (synth.longitudinal, dict(nsubj=50, nvisit=4))):
+    for gen, kw in ((synth.stepped_wedge, dict(ncl=9, nt=6, nind=12)), (synth.longitudinal, dict(nsubj=50, nvisit=4)),
+                    (synth.stepped_wedge, dict(ncl=7, nt=5, nind=40))):      # long rows of ZL' (config 4's regime)
         d = gen(**kw)
         out = {}
         for mode in ("sparse", "dense"):

@@ -1,0 +1,144 @@
+"""The N > 1 path of the PRODUCT (csrc/comm.hip, model.hip::model_mcnr_stats, drivers.hip: chain_offset =
+rank * chains, every statistic all-reduced) on one GPU:
+
+  * two contexts, rank 0 and rank 1 of world 2, driven from two host threads; the reduce hook sums the two
+    contexts' device buffers (fixed order, barrier either side) -- what RCCL does between two GPUs.  mcml_full
+    over 2 x C chains must reproduce the single-context run with 2C chains (src/mcml_full.cpp:83-145): beta,
+    theta, sigma, and each rank's u = its columns of the unsharded u; the number of collectives and their payloads
+    are the ones DESIGN.md section 7 states (P*P+P+2 doubles per MCNR step, 2 per objective evaluation);
+  * the native RCCL communicator (ncclAllReduce on the context's stream, no callback) on a 1-rank group: same
+    numbers as no communicator, collectives counted.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from glmmrmcml_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+class _DevArray:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def _run_world2(d, kw, C):
+    import torch
+    from glmmrmcml_amd import api
+    args = (d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"])
+    bar = threading.Barrier(2, timeout=120)
+    slots = [None, None]
+    calls = [[], []]
+
+    def make_hook(rank):
+        def hook(user, ptr, n):
+            try:
+                t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
+                slots[rank] = t.clone()
+                torch.cuda.synchronize()
+                bar.wait()
+                tot = slots[0] + slots[1]            # the same order on both ranks: bit-identical sums
+                t.copy_(tot)
+                torch.cuda.synchronize()
+                calls[rank].append(int(n))
+                bar.wait()
+                return 0
+            except Exception as e:                   # never raise through the C frame
+                print("hook failed:", repr(e), flush=True)
+                bar.abort()
+                return 1
+        return hook
+
+    out = [None, None]
+    err = [None, None]
+
+    def worker(rank):
+        try:
+            with api.Context(*args, rank=rank, world=2, reduce=make_hook(rank)) as ctx:
+                r = ctx.mcml_full(d["start"], chains=C, m=C, **kw)
+                r["u"] = ctx.get_u()
+                r["comm"] = ctx.comm_stats()
+                out[rank] = r
+        except Exception as e:
+            err[rank] = e
+            bar.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    assert err == [None, None], err
+    return out, calls
+
+
+@pytest.mark.parametrize("gen,gkw,mcnr", [(synth.cluster_rct, dict(ncl=8, nt=3, nind=6, seed=3), True),
+                                          (synth.geospatial, dict(n=150, seed=9), True),
+                                          (synth.cluster_rct, dict(ncl=8, nt=3, nind=6, seed=3), False)])
+def test_world2_contexts_equal_one_context_with_all_chains(gen, gkw, mcnr):
+    from glmmrmcml_amd import api
+    d = gen(**gkw)
+    C = 12
+    # the optimisers run to convergence (default budget): a truncated trust-region run is path dependent, and the
+    # sharded objective differs from the unsharded one in the last bits (sum over ranks of per-rank sums)
+    kw = dict(mcnr=mcnr, maxiter=2, warmup=15, tol=1e-12, lambda_=0.3, maxsteps=6, target_accept=0.9, seed=4242)
+    args = (d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"])
+    with api.Context(*args) as ctx:
+        whole = ctx.mcml_full(d["start"], chains=2 * C, m=2 * C, **kw)
+        whole["u"] = ctx.get_u()
+        assert ctx.comm_stats()["calls"] == 0
+    out, calls = _run_world2(d, kw, C)
+    P = d["P"]
+    for r in range(2):
+        assert out[r]["iters"] == 2
+        assert np.abs(out[r]["beta"] - whole["beta"]).max() < 2e-6 * max(1.0, np.abs(whole["beta"]).max())
+        assert np.abs(out[r]["theta"] - whole["theta"]).max() < 2e-6
+        assert abs(out[r]["sigma"] - whole["sigma"]) < 2e-6 * max(1.0, abs(whole["sigma"]))
+        # rank r holds global chains [r*C, (r+1)*C): one draw per chain -> its columns of the unsharded u
+        assert out[r]["u"].shape == (d["Q"], C)
+        assert np.abs(out[r]["u"] - whole["u"][:, r * C:(r + 1) * C]).max() < 2e-5
+        assert not out[r]["comm"]["native"] and out[r]["comm"]["calls"] == len(calls[r])
+    assert np.array_equal(out[0]["beta"], out[1]["beta"]) and np.array_equal(out[0]["theta"], out[1]["theta"])
+    assert calls[0] == calls[1] and len(calls[0]) > 0
+    if mcnr:
+        # per iteration: one MCNR statistics collective, then (sum, count) per theta evaluation
+        assert calls[0].count(P * P + P + 2) == 2
+        assert set(calls[0]) == {P * P + P + 2, 2}
+        assert calls[0].count(2) >= 2 * 5
+    else:
+        assert set(calls[0]) == {2}
+
+
+def test_world_gt_1_without_exchange_is_an_error():
+    from glmmrmcml_amd import api, _lib
+    d = synth.cluster_rct(ncl=4, nt=2, nind=3, seed=1)
+    args = (d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"])
+    with api.Context(*args, rank=0, world=2) as ctx:
+        ctx.set_u(np.zeros((d["Q"], 3)))
+        with pytest.raises(_lib.McmlError, match="neither an RCCL communicator"):
+            ctx.mvn_ll(d["theta"])
+
+
+def test_native_rccl_single_rank_group():
+    """glmmr_mcml_ctx_comm_init_rccl on a 1-rank communicator: every statistic goes through ncclAllReduce on the
+    context's stream (identity sum) -- same results as without it, collectives counted"""
+    from glmmrmcml_amd import api
+    d = synth.cluster_rct(ncl=8, nt=3, nind=6, seed=3)
+    args = (d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"])
+    kw = dict(mcnr=True, maxiter=2, warmup=15, tol=1e-12, lambda_=0.3, maxsteps=6, target_accept=0.9, seed=7,
+              maxfun=20, chains=10, m=10)
+    with api.Context(*args) as ctx:
+        base = ctx.mcml_full(d["start"], **kw)
+        ub = ctx.get_u()
+    with api.Context(*args) as ctx:
+        ctx.comm_init_rccl(api.rccl_unique_id(), 0, 1)
+        got = ctx.mcml_full(d["start"], **kw)
+        ug = ctx.get_u()
+        st = ctx.comm_stats()
+        ll = ctx.mvn_ll(got["theta"])
+        assert ctx.comm_stats()["calls"] == st["calls"] + 1
+    assert st["native"] and st["calls"] >= 4 and st["doubles"] >= 2 * (d["P"] ** 2 + d["P"] + 2)
+    assert np.array_equal(got["beta"], base["beta"]) and np.array_equal(got["theta"], base["theta"])
+    assert np.array_equal(ug, ub) and np.isfinite(ll)

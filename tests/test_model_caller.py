@@ -240,3 +240,18 @@ def test_print_table_formulas_against_the_reference_readme():
     # duplicated names get .1 / .2 suffixes as print.mcml does
     names = [r[0] for r in rows]
     assert names.count("int.1") == 1 and names.count("int.2") == 1 and names.count("t4.1") == 1
+
+
+_FAMLINK = [("poisson", "log"), ("poisson", "identity"), ("binomial", "logit"), ("binomial", "log"),
+            ("binomial", "identity"), ("binomial", "probit"), ("gaussian", "identity"), ("gaussian", "log"),
+            ("gamma", "log"), ("gamma", "inverse"), ("gamma", "identity"), ("beta", "logit")]
+
+
+@pytest.mark.parametrize("k", range(12))
+def test_dhdmu_is_one_table(orc, k):
+    """the caller's gen_dhdmu restatement equals the oracle's maths::dhdmu restatement (and so csrc/glm.h's, which the
+    GPU parity tests compare with the oracle) for every family/link case"""
+    fam, link = _FAMLINK[k]
+    assert orc.flink(fam, link) == k + 1          # mcmlmodel.h:83-85: the map keys are lower-case "gamma..."
+    eta = np.linspace(0.05, 0.9, 9) if link in ("identity", "inverse") else np.linspace(-1.2, 1.1, 9)
+    assert np.allclose(_dhdmu(eta, fam, link), orc.dhdmu(eta, k + 1), rtol=1e-14, atol=0)

@@ -159,3 +159,29 @@ def test_model_loglik_mean_over_columns(orc):
     assert abs(got - want) < 1e-10 * abs(want)
     # the D5 quirk: the beta-step reads only the first niter_ columns
     assert orc.model_loglik(d["Z"], xb, d["y"], u, 1.0, 3, ncols=3) != got
+
+
+def test_digamma_vs_scipy(orc):
+    """orc_digamma stands where boost::math::digamma is called (mcmlmodel.h:271): recurrence to x >= 10 plus the
+    asymptotic series.  Known answers: psi(1) = -gamma, psi(1/2) = -gamma - 2 ln 2, scipy elsewhere."""
+    from scipy.special import digamma
+    assert orc.digamma(1.0) == pytest.approx(-0.57721566490153286, abs=2e-15)
+    assert orc.digamma(0.5) == pytest.approx(-0.57721566490153286 - 2 * np.log(2.0), abs=4e-15)
+    for x in np.concatenate([np.geomspace(1e-3, 50.0, 60), [9.999, 10.0, 10.001, 123.4]]):
+        assert orc.digamma(x) == pytest.approx(float(digamma(x)), rel=2e-14, abs=2e-14)
+    assert np.isnan(orc.digamma(0.0)) and np.isnan(orc.digamma(-1.5))
+
+
+def test_beta_score_is_the_reference_expression(orc):
+    """flink 12 (mcmlmodel.h:266-275): with ZL = I and xb = 0 the gradient is -v + s, s the per-observation expression,
+    which reads the UPDATED mu(i) = p in its leading factor: p/(1+exp(p)), reproduced literally"""
+    from scipy.special import digamma
+    rng = np.random.default_rng(4)
+    n = 7
+    v = rng.normal(size=n) * 0.4
+    y = rng.uniform(0.1, 0.9, size=n)
+    phi = 3.5
+    g = orc.log_grad(np.zeros(n), np.eye(n), y, phi, 12, v)
+    p = np.exp(v) / (np.exp(v) + 1)
+    s = (p / (1 + np.exp(p))) * phi * (np.log(y) - np.log(1 - y) - digamma(p * phi) + digamma((1 - p) * phi))
+    assert np.allclose(g, -v + s, rtol=1e-12, atol=1e-13)

@@ -5,11 +5,17 @@ metric : MCML iters/sec x m chains (simlik evals/sec)
 step   : one MCML iteration = one pass of the `while` body of mcml_full
          (src/mcml_full.cpp:83-140): draw the samples (HMC) + beta-step (MCNR) +
          theta-step (BOBYQA on the MVN log-likelihood) + L refresh.
-workload (every N): Gaussian geospatial, n = Q = 5000, ~(1|fexp(x,y)), dense Sigma,
-         m = 1024 chains PER GPU (weak scaling: chains shard over ranks, ZL/X/y/L
-         replicated, one RCCL all-reduce of the statistics per evaluation),
-         HMC warmup 100 + 1 draw per chain, 10 leapfrog steps, theta-step budget 40
-         objective evaluations.  Synthetic data, seed 20240601.
+workload (every N): BASELINE config 3 as written -- Gaussian geospatial, n = Q = 5000,
+         ~(1|fexp(x,y)), dense Sigma, MCNR, m = 1024 chains IN TOTAL, sharded over the N
+         GPUs (STRONG scaling: rank r owns global chains [r m/N, (r+1) m/N); ZL/X/y/L
+         replicated; one RCCL all-reduce of the statistics per evaluation), HMC warmup
+         100 + 1 draw per chain, 10 leapfrog steps, theta-step budget 40 objective
+         evaluations.  Synthetic data, seed 20240601.
+         --weak keeps m = 1024 chains PER GPU instead ("scaling": "weak").
+         --chains C overrides the chains per GPU (e.g. --gpus 1 --chains 128 = what one
+         rank of the 8-GPU job runs).
+         --dense-z replaces Z = I by a dense orthogonal-like Z (ZL dense: no zero
+         skipping) -- a second, clearly labelled workload, not the metric's.
 Inputs are resident in HBM before the timed region starts.
 
 Launch: python bench.py --gpus 1 --steps K --warmup W      (single GPU)
@@ -28,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix, vendor figure (SURVEY.md 8d / BASELINE.md)
 
-CFG = dict(n=5000, chains_per_gpu=1024, hmc_warmup=100, max_steps=10, lambda_=5.0, target_accept=0.9,
+CFG = dict(n=5000, chains_total=1024, chains_per_gpu=1024, hmc_warmup=100, max_steps=10, lambda_=5.0, target_accept=0.9,
            theta_maxfun=40, seed=20240601)
 
 
@@ -42,7 +48,7 @@ def cpu_baseline(d, cfg, budget_props=30):
     except Exception:                                   # pragma: no cover
         threadpool_limits = None
     threads = orc.num_threads()
-    n = cfg["n"]; m = cfg["chains_per_gpu"]; W = cfg["hmc_warmup"]; E = cfg["theta_maxfun"]
+    n = cfg["n"]; m = cfg["chains_total_run"]; W = cfg["hmc_warmup"]; E = cfg["theta_maxfun"]
     ctxmgr = threadpool_limits(limits=threads) if threadpool_limits else None
     if ctxmgr is not None:
         ctxmgr.__enter__()
@@ -55,7 +61,7 @@ def cpu_baseline(d, cfg, budget_props=30):
         U = np.asfortranarray(L @ rng.standard_normal((n, 64)))
         t0 = time.time(); sla.solve_triangular(L, U, lower=True); t_trsm64 = time.time() - t0
         t0 = time.time(); ZU = d["Z"] @ U; t_zu64 = time.time() - t0                    # Z*u, 64 columns
-        ZL = np.asfortranarray(L)                                                        # Z = I
+        ZL = np.asfortranarray(d["Z"] @ L) if cfg.get("dense_z") else np.asfortranarray(L)  # Z = I
         xb = d["X"] @ d["beta"]
         t0 = time.time()
         orc.hmc_chain(xb, ZL, d["y"], d["sigma"], 7, budget_props - 1, 1, cfg["lambda_"], cfg["max_steps"],
@@ -91,7 +97,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n", "--nobs", dest="n", type=int, default=CFG["n"], help="override n = Q (debug only; invalidates the metric)")
-    ap.add_argument("--chains", type=int, default=CFG["chains_per_gpu"])
+    ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: 1024 / gpus; with --weak 1024)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: 1024 chains per GPU")
+    ap.add_argument("--reduce", choices=("native", "torch"), default="native",
+                    help="N > 1: the library's own RCCL communicator (default) or the torch.distributed hook")
+    ap.add_argument("--dense-z", action="store_true", help="dense (non-identity) Z: ZL dense, no zero skipping")
     args = ap.parse_args()
 
     import torch
@@ -120,14 +130,42 @@ def main():
             tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             tdist.init_process_group(backend=backend)
-        hook = gdist.make_reduce_hook()
+        if args.reduce == "torch" or backend != "nccl":
+            hook = gdist.make_reduce_hook()
 
-    cfg = dict(CFG); cfg["n"] = args.n; cfg["chains_per_gpu"] = args.chains
+    cfg = dict(CFG); cfg["n"] = args.n
+    if args.chains > 0:
+        cfg["chains_per_gpu"] = args.chains
+    elif args.weak:
+        cfg["chains_per_gpu"] = CFG["chains_total"]
+    else:
+        assert CFG["chains_total"] % world == 0, "1024 chains do not divide over %d ranks" % world
+        cfg["chains_per_gpu"] = CFG["chains_total"] // world
+    scaling = "weak" if (args.weak or args.chains > 0) else "strong"
     n, C = cfg["n"], cfg["chains_per_gpu"]
     d = synth.geospatial(n, seed=cfg["seed"])
+    if args.dense_z:
+        # a dense, well-conditioned Z (Householder reflector): ZL = Z L has no structural zeros
+        rng = np.random.default_rng(cfg["seed"] + 1)
+        v = rng.standard_normal(n); v /= np.linalg.norm(v)
+        d["Z"] = np.asfortranarray(np.eye(n) - 2.0 * np.outer(v, v))
     stream = torch.cuda.current_stream().cuda_stream
     ctx = api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"],
                       device=local_rank, stream=stream, rank=rank, world=world, reduce=hook)
+    collective = "none (single process)"
+    if world > 1:
+        collective = "torch.distributed all_reduce hook (%s)" % backend
+        if hook is None:
+            try:
+                gdist.init_native_rccl(ctx, rank, world)
+                collective = "librccl ncclAllReduce on the library's stream (native, no host sync)"
+            except Exception as e:          # a different GPU collective, not a CPU path: say which one ran
+                print("bench: native RCCL communicator failed (%r); using the torch.distributed hook" % (e,),
+                      file=sys.stderr, flush=True)
+                ctx.close()
+                hook = gdist.make_reduce_hook()
+                ctx = api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"],
+                                  d["link"], device=local_rank, stream=stream, rank=rank, world=world, reduce=hook)
 
     def run(iters):
         return ctx.mcml_full(d["start"], mcnr=True, m=C, maxiter=iters, warmup=cfg["hmc_warmup"], tol=0.0,
@@ -165,11 +203,17 @@ def main():
         executed = prof["fwd_flops"] * prof["fwd_n"] + prof["bwd_flops"] * prof["bwd_n"]
         achieved = executed / gemm_s / 1e12 if launches else 0.0
         dense_equiv = prof["dense_flops"] * launches / gemm_s / 1e12 if launches else 0.0
-        traffic = None
-        pj = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(pj) and n == CFG["n"] and C == CFG["chains_per_gpu"]:
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md "HBM"): a
+        # separate rocprofv3 --pmc run of this same command (scripts/pmc_traffic.py writes the json); quoted
+        # only when it was taken on this workload, with the file it came from
+        traffic = None; traffic_src = None
+        pj = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+        if os.path.exists(pj):
             try:
-                traffic = json.load(open(pj)).get("hbm_bytes_per_launch_%s" % prof["operator"])
+                tj = json.load(open(pj))
+                if tj.get("n") == n and tj.get("chains") == C and bool(tj.get("dense_z")) == bool(args.dense_z):
+                    traffic = tj.get("hbm_bytes_per_launch_%s" % prof["operator"])
+                    traffic_src = "profiles/r02_hbm_traffic.json (%s)" % tj.get("build", "?")
             except Exception:
                 traffic = None
         line = {
@@ -178,18 +222,20 @@ def main():
             "unit": "simlik evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "gaussian geospatial n=Q=%d fexp dense Sigma, MCNR, m=%d chains per GPU "
+            "config": {"workload": "gaussian geospatial n=Q=%d fexp dense Sigma%s, MCNR, m=%d chains in total = %d per GPU "
                                    "(HMC warmup %d + 1 draw/chain, %d leapfrog steps), theta-step BOBYQA budget %d evals"
-                                   % (n, C, cfg["hmc_warmup"], cfg["max_steps"], cfg["theta_maxfun"]),
+                                   % (n, " with a DENSE Z (not the metric's Z = I)" if args.dense_z else "", C * world, C,
+                                      cfg["hmc_warmup"], cfg["max_steps"], cfg["theta_maxfun"]),
                        "n": n, "Q": n, "m_per_gpu": C, "m_total": C * world, "parallelism": "chains x%d" % world,
+                       "collective": collective,
                        "accept_rate": res["accept_rate"], "leapfrog_steps_last_iter": res["leapfrog_total"]},
             "roofline": {"bound": "mfma",
                          "kernel": "dgemm_%s_kernel (HMC forward / backward n x Q x C product, FP64 MFMA)"
                                    % ("band" if prof["operator"] == "banded" else "dlds"),
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": launches, "avg_launch_ms": avg_s * 1e3,
                          "flops_per_launch_executed": executed / max(1, launches),
                          "flops_per_launch_dense_2nQC": prof["dense_flops"],
@@ -201,6 +247,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
+                cfg["chains_total_run"] = C * world; cfg["dense_z"] = bool(args.dense_z)
                 line["cpu_baseline"] = cpu_baseline(d, cfg)
             except Exception as e:           # the baseline never blocks the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "simlik evals/s", "cores": 0, "kind": "port",

@@ -62,26 +62,46 @@ struct EpiForwardT {
         if (store_mu) MU[m + (size_t)n * ld] = mu;
         S[m + (size_t)n * ld] = score(y[m], mu);
     }
+    // Three phases -- all loads, all arithmetic, all stores -- with no use of a loaded register after the first
+    // store.  The compiler's waitcnt insertion cannot count stores issued under divergent control flow, so any
+    // such use gets `s_waitcnt vmcnt(0)`, and vector memory completes in order: that wait also drains every store
+    // issued so far (one memory round trip per row group, ~1-2 us each with every CU storing at once).
     template <int TM, int TN>
     __device__ __forceinline__ void operator()(d4 (&acc)[TM][TN], int mB, int nB, int lane, int M, int N,
                                                int) const {
+        double xbv[TM], yv[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = mB + 16 * i + (lane & 15);
-            if (m >= M) continue;
-            const double xbi = xb[m], yi = y[m];
+            const int mm = m < M ? m : 0;
+            xbv[i] = xb[mm]; yv[i] = y[mm];
+        }
+        double sc[TM][TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int n = nB + 16 * j + (lane >> 4) + 4 * r;
-                    if (n < N) {
-                        const double mu = xbi + acc[i][j][r];
-                        if (store_mu) MU[m + (size_t)n * ld] = mu;
-                        S[m + (size_t)n * ld] = score(yi, mu);
+                    const double mu = xbv[i] + acc[i][j][r];
+                    acc[i][j][r] = mu;
+                    sc[i][j][r] = score(yv[i], mu);
+                }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nB + 16 * j + (lane >> 4) + 4 * r;
+                if (n >= N) continue;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int m = mB + 16 * i + (lane & 15);
+                    if (m < M) {
+                        if (store_mu) MU[m + (size_t)n * ld] = acc[i][j][r];
+                        S[m + (size_t)n * ld] = sc[i][j][r];
                     }
                 }
-        }
+            }
     }
 };
 
@@ -109,23 +129,24 @@ struct EpiBackward {
             R[off] = rr;
         }
     }
-    // All loads of a 16-column group are issued (from clamped, always valid addresses) before the first
-    // use, so the epilogue pays one memory round trip instead of one per element; only the stores
-    // are predicated.  Arithmetic order per element is elem()'s.
+    // Per 16-column group: all loads (from clamped, always valid addresses), then all arithmetic into
+    // registers, then all stores, and no use of a loaded register after the first store (see EpiForwardT: such a
+    // use costs `s_waitcnt vmcnt(0)`, which drains the stores issued so far -- one memory round trip per
+    // element group).  Arithmetic order per element is elem()'s; the choices it makes with branches are selects.
     template <int TM, int TN>
     __device__ __forceinline__ void operator()(d4 (&acc)[TM][TN], int mB, int nB, int lane, int M, int N,
                                                int) const {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            int stv[4]; double env[4]; bool act[4]; size_t cb[4];
+            int stv[4]; double env[4]; bool inN[4]; size_t cb[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = nB + 16 * j + (lane >> 4) + 4 * r;
-                bool a = n < N;
-                const int nn = a ? n : 0;
-                int st_ = 0; double en_ = 0.0;
-                if (mode == 1) { st_ = steps[nn]; en_ = e[nn]; a = a && s < st_; }
-                act[r] = a; stv[r] = st_; env[r] = en_; cb[r] = (size_t)nn * ld;
+                inN[r] = n < N;
+                const int nn = inN[r] ? n : 0;
+                stv[r] = mode == 1 ? steps[nn] : 0;
+                env[r] = mode == 1 ? e[nn] : 0.0;
+                cb[r] = (size_t)nn * ld;
             }
             double xv[TM][4], rv[TM][4];
 #pragma unroll
@@ -138,27 +159,39 @@ struct EpiBackward {
                     rv[i][r] = mode == 1 ? R[mm + cb[r]] : 0.0;
                 }
             }
+            // g -> acc, new R -> rv, new UP -> xv
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (!act[r]) continue;
-                const int st = stv[r]; const double en = env[r];
+                const double en = env[r];
+                const bool more = s + 1 < stv[r];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const double x = xv[i][r];
+                    double g = -1.0 * x;
+                    g = g + post * acc[i][j][r];
+                    acc[i][j][r] = g;
+                    double rr = rv[i][r];
+                    rr = rr + (en / 2) * g;
+                    const double rr2 = rr + (en / 2) * g;
+                    rr = more ? rr2 : rr;
+                    rv[i][r] = rr;
+                    xv[i][r] = x + en * rr;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool act = inN[r] && (mode != 1 || s < stv[r]);
+                if (!act) continue;
+                const bool more = s + 1 < stv[r];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int m = mB + 16 * i + (lane & 15);
                     if (m >= M) continue;
                     const size_t off = m + cb[r];
-                    const double x = xv[i][r];
-                    double g = -1.0 * x;
-                    g = g + post * acc[i][j][r];
-                    if (mode != 1 || s + 1 >= st) G[off] = g;
+                    if (mode != 1 || !more) G[off] = acc[i][j][r];       // mid-trajectory gradients are never read
                     if (mode == 1) {
-                        double rr = rv[i][r];
-                        rr = rr + (en / 2) * g;
-                        if (s + 1 < st) {
-                            rr = rr + (en / 2) * g;
-                            UP[off] = x + en * rr;
-                        }
-                        R[off] = rr;
+                        if (more) UP[off] = xv[i][r];
+                        R[off] = rv[i][r];
                     }
                 }
             }

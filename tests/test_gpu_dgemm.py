@@ -111,8 +111,12 @@ def _check_band(A, B):
     return tiles
 
 
+# N = 1024 at M = 5000 runs the paired decomposition (one workgroup per CU, no partial sums); every other shape the
+# streamed one (the (band, K tile) space cut into equal runs + k_band_reduce): N = 128 is one rank of the chain-sharded
+# config 3 (1024 chains over 8 GPUs), N = 512 / 256 its 2- and 4-GPU forms
 @pytest.mark.parametrize("M,N,K", [(5000, 1024, 5000), (80, 128, 32), (81, 129, 33), (333, 77, 250), (1000, 1, 999),
-                                   (160, 300, 2000), (2000, 256, 2000)])
+                                   (160, 300, 2000), (2000, 256, 2000), (5000, 128, 5000), (5000, 512, 5000),
+                                   (5000, 256, 5000), (5000, 896, 5000)])
 def test_band_lower_triangular(M, N, K):
     rng = np.random.default_rng(M + N + K)
     A = np.tril(rng.normal(size=(M, K)))
@@ -143,3 +147,16 @@ def test_band_general_band_and_empty_bands():
     assert tiles < 0.35 * ((M + 79) // 80) * ((K + 31) // 32)
     got, _ = _band(A, rng.normal(size=(K, N)))
     assert np.all(got[400:560, :] == 0.0)
+
+
+def test_band_streamed_reduction_is_bit_reproducible():
+    """the second stage sums a band's pieces in K order: two launches give identical bits"""
+    rng = np.random.default_rng(5)
+    A = np.tril(rng.normal(size=(2500, 2500)))
+    B = rng.normal(size=(2500, 128))
+    g1, _ = _band(A, B)
+    g2, _ = _band(A, B)
+    assert np.array_equal(g1, g2)
+    g3, _ = _band(np.triu(A.T), B)
+    g4, _ = _band(np.triu(A.T), B)
+    assert np.array_equal(g3, g4)

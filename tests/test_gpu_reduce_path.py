@@ -9,6 +9,7 @@ rank * chains, every statistic all-reduced) on one GPU:
   * the native RCCL communicator (ncclAllReduce on the context's stream, no callback) on a 1-rank group: same
     numbers as no communicator, collectives counted.
 """
+import ctypes as C
 import threading
 
 import numpy as np
@@ -19,29 +20,36 @@ from glmmrmcml_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-class _DevArray:
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+_HIP = None
 
 
-def _run_world2(d, kw, C):
-    import torch
+def _hip():
+    """the HIP runtime through ctypes: the hook moves its few doubles with plain (synchronous) hipMemcpy"""
+    global _HIP
+    if _HIP is None:
+        _HIP = C.CDLL("libamdhip64.so")
+        _HIP.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _HIP.hipMemcpy.restype = C.c_int
+    return _HIP
+
+
+def _run_world2(d, kw, Cn):
     from glmmrmcml_amd import api
     args = (d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"])
     bar = threading.Barrier(2, timeout=120)
     slots = [None, None]
     calls = [[], []]
+    hip = _hip()
 
     def make_hook(rank):
         def hook(user, ptr, n):
             try:
-                t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
-                slots[rank] = t.clone()
-                torch.cuda.synchronize()
+                mine = np.zeros(n)
+                assert hip.hipMemcpy(mine.ctypes.data, ptr, 8 * n, 2) == 0          # device -> host
+                slots[rank] = mine
                 bar.wait()
                 tot = slots[0] + slots[1]            # the same order on both ranks: bit-identical sums
-                t.copy_(tot)
-                torch.cuda.synchronize()
+                assert hip.hipMemcpy(ptr, tot.ctypes.data, 8 * n, 1) == 0           # host -> device
                 calls[rank].append(int(n))
                 bar.wait()
                 return 0
@@ -57,7 +65,7 @@ def _run_world2(d, kw, C):
     def worker(rank):
         try:
             with api.Context(*args, rank=rank, world=2, reduce=make_hook(rank)) as ctx:
-                r = ctx.mcml_full(d["start"], chains=C, m=C, **kw)
+                r = ctx.mcml_full(d["start"], chains=Cn, m=Cn, **kw)
                 r["u"] = ctx.get_u()
                 r["comm"] = ctx.comm_stats()
                 out[rank] = r
@@ -80,16 +88,16 @@ def _run_world2(d, kw, C):
 def test_world2_contexts_equal_one_context_with_all_chains(gen, gkw, mcnr):
     from glmmrmcml_amd import api
     d = gen(**gkw)
-    C = 12
+    Cn = 12
     # the optimisers run to convergence (default budget): a truncated trust-region run is path dependent, and the
     # sharded objective differs from the unsharded one in the last bits (sum over ranks of per-rank sums)
     kw = dict(mcnr=mcnr, maxiter=2, warmup=15, tol=1e-12, lambda_=0.3, maxsteps=6, target_accept=0.9, seed=4242)
     args = (d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"])
     with api.Context(*args) as ctx:
-        whole = ctx.mcml_full(d["start"], chains=2 * C, m=2 * C, **kw)
+        whole = ctx.mcml_full(d["start"], chains=2 * Cn, m=2 * Cn, **kw)
         whole["u"] = ctx.get_u()
         assert ctx.comm_stats()["calls"] == 0
-    out, calls = _run_world2(d, kw, C)
+    out, calls = _run_world2(d, kw, Cn)
     P = d["P"]
     for r in range(2):
         assert out[r]["iters"] == 2
@@ -97,8 +105,8 @@ def test_world2_contexts_equal_one_context_with_all_chains(gen, gkw, mcnr):
         assert np.abs(out[r]["theta"] - whole["theta"]).max() < 2e-6
         assert abs(out[r]["sigma"] - whole["sigma"]) < 2e-6 * max(1.0, abs(whole["sigma"]))
         # rank r holds global chains [r*C, (r+1)*C): one draw per chain -> its columns of the unsharded u
-        assert out[r]["u"].shape == (d["Q"], C)
-        assert np.abs(out[r]["u"] - whole["u"][:, r * C:(r + 1) * C]).max() < 2e-5
+        assert out[r]["u"].shape == (d["Q"], Cn)
+        assert np.abs(out[r]["u"] - whole["u"][:, r * Cn:(r + 1) * Cn]).max() < 2e-5
         assert not out[r]["comm"]["native"] and out[r]["comm"]["calls"] == len(calls[r])
     assert np.array_equal(out[0]["beta"], out[1]["beta"]) and np.array_equal(out[0]["theta"], out[1]["theta"])
     assert calls[0] == calls[1] and len(calls[0]) > 0

@@ -59,30 +59,43 @@ struct BandPlan {
             wg_ptr.push_back((int)items.size());
             return;
         }
+        // Streamed: walk the bands in order and fill one workgroup after another up to a cost cap.  Cost in
+        // half K tiles: 2 per K tile + OVH per item (ring fill, barrier, epilogue or partial store: measured
+        // ~2.5 K tiles' worth, so a workgroup that sweeps up several short bands gets fewer K tiles).  The cap is
+        // the smallest one whose greedy fill needs at most nwg workgroups (bisection).
+        int nwg = target_wg / gn; if (nwg < 1) nwg = 1;
+        constexpr long OVH = 5;
+        auto fill = [&](long cap, bool emit) -> int {
+            int used = 1; long room = cap;
+            if (emit) wg_ptr.push_back(0);
+            for (int b = 0; b < nbands; ++b) {
+                int k0 = kr[2 * b]; const int k1 = kr[2 * b + 1];
+                const int first = (int)items.size();
+                int pieces = 0;
+                do {
+                    if (room < OVH + 2) { ++used; room = cap; if (emit) wg_ptr.push_back((int)items.size()); }
+                    long take = (room - OVH) / 2; if (take > k1 - k0) take = k1 - k0;
+                    if (emit) items.push_back({b, k0, k0 + (int)take, -1});
+                    k0 += (int)take; room -= OVH + 2 * take; ++pieces;
+                } while (k0 < k1);
+                if (emit && pieces > 1) {
+                    for (int t = 0; t < pieces; ++t) items[first + t].slot = nslots + t;
+                    red.push_back({b, nslots, nslots + pieces, 0});
+                    nslots += pieces;
+                }
+            }
+            if (emit) wg_ptr.push_back((int)items.size());
+            return used;
+        };
         long T = 0;
         for (int b = 0; b < nbands; ++b) T += kr[2 * b + 1] - kr[2 * b];
-        int nwg = target_wg / gn; if (nwg < 1) nwg = 1;
-        long per = (T + nwg - 1) / nwg; if (per < 1) per = 1;
-        // a band without nonzero tiles still needs its epilogue (acc = 0): give it a zero-length item
-        long room = per;                       // K tiles the current workgroup can still take
-        wg_ptr.push_back(0);
-        for (int b = 0; b < nbands; ++b) {
-            int k0 = kr[2 * b]; const int k1 = kr[2 * b + 1];
-            const int first = (int)items.size();
-            do {
-                if (room == 0) { wg_ptr.push_back((int)items.size()); room = per; }
-                const int take = (int)std::min<long>(room, k1 - k0);
-                items.push_back({b, k0, k0 + take, -1});
-                k0 += take; room -= take;
-            } while (k0 < k1);
-            const int npieces = (int)items.size() - first;
-            if (npieces > 1) {
-                for (int t = 0; t < npieces; ++t) items[first + t].slot = nslots + t;
-                red.push_back({b, nslots, nslots + npieces, 0});
-                nslots += npieces;
-            }
+        long lo = OVH + 2, hi = 2 * T + OVH * nbands + OVH + 2;      // hi: everything in one workgroup
+        while (lo < hi) {
+            const long mid = (lo + hi) / 2;
+            if (fill(mid, false) <= nwg) hi = mid; else lo = mid + 1;
         }
-        wg_ptr.push_back((int)items.size());
+        fill(lo, true);
+        return;
     }
 
     int device_plan(int gn, hipStream_t s, BandPlanDev** out)

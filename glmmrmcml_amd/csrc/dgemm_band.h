@@ -366,15 +366,26 @@ __global__ __launch_bounds__(128) void k_band_reduce(const BandRed* red, const d
     d4 acc[5][1];
 #pragma unroll
     for (int i = 0; i < 5; ++i) acc[i][0] = d4{0.0, 0.0, 0.0, 0.0};
-    for (int s = rd.s0; s < rd.s1; ++s) {
-        const double* P = part + ((size_t)s * gn + bj) * BD_TILE_ELEMS + (size_t)wave * (20 * 64) + lane;
-        double v[20];
+    // four pieces' loads in flight at a time (the kernel is latency-bound: a handful of pieces per band); the adds
+    // stay in K order
+    const size_t pstride = (size_t)gn * BD_TILE_ELEMS;
+    const double* P0 = part + ((size_t)rd.s0 * gn + bj) * BD_TILE_ELEMS + (size_t)wave * (20 * 64) + lane;
+    for (int s = rd.s0; s < rd.s1; s += 4) {
+        double v[4][20];
 #pragma unroll
-        for (int t = 0; t < 20; ++t) v[t] = P[t * 64];
+        for (int u = 0; u < 4; ++u) {
+            const double* P = P0 + (size_t)(s - rd.s0 + (s + u < rd.s1 ? u : 0)) * pstride;
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
+            for (int t = 0; t < 20; ++t) v[u][t] = P[t * 64];
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][0][r] += v[i * 4 + r];
+        for (int u = 0; u < 4; ++u)
+            if (s + u < rd.s1) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][0][r] += v[u][i * 4 + r];
+            }
     }
     epi(acc, rd.band * BD_BM, bj * BD_BN + wave * 16, lane, M, N, rd.band);
 }

@@ -87,20 +87,22 @@ __global__ __launch_bounds__(64 * WM * WN) void dgemm_dl_kernel(GemmP p, Epi epi
     const int m0 = bi * BM, n0 = bj * BN;
     if (p.lower_only && n0 >= m0 + BM) return;             // whole workgroup, before any barrier
 
-    // ---- this wave's LDS-DMA pieces: per-lane source pointer, LDS offset, per-K-step stride
-    const double* src[PER]; int loff[PER]; size_t step[PER];
+    // ---- this wave's LDS-DMA pieces: a uniform base per operand (advanced per K step by scalar adds) plus a
+    // per-lane 32-bit byte offset that never changes (lds_dma16, dgemm_dlds.h); piece s of a wave belongs to A
+    // or to B depending on the wave only, so the choice of base is scalar
+    unsigned voff[PER]; int loff[PER]; bool isA[PER];
 #pragma unroll
     for (int s = 0; s < PER; ++s) {
         int c = wave + NW * s;
         if (c >= Cfg::CHUNKS) c = wave;                    // repeat a piece: uniform vmcnt bookkeeping
+        isA[s] = c < Cfg::A_CHUNKS;
         if (c < Cfg::A_CHUNKS) {
             const int o = c * 1024 + lane * 16;
             const int k = o / (BM * 8), pos = (o - k * BM * 8) >> 3;
             const int m = Cfg::SWZ_A ? ((((pos >> 4) ^ (k & 1)) << 4) | (pos & 15)) : pos;
             int gm = m0 + m;
             if (gm >= p.M) gm = 0;
-            src[s] = p.A + gm + (size_t)k * p.lda;
-            step[s] = (size_t)BK * p.lda;
+            voff[s] = (unsigned)((gm + (size_t)k * p.lda) * 8);
             loff[s] = c * 1024;
         } else {
             const int cb = c - Cfg::A_CHUNKS;
@@ -110,31 +112,27 @@ __global__ __launch_bounds__(64 * WM * WN) void dgemm_dl_kernel(GemmP p, Epi epi
                 const int n = Cfg::SWZ_B ? ((((pos >> 4) ^ (k & 1)) << 4) | (pos & 15)) : pos;
                 int gn = n0 + n;
                 if (gn >= p.N) gn = 0;
-                src[s] = p.B + gn + (size_t)k * p.ldb;
-                step[s] = (size_t)BK * p.ldb;
+                voff[s] = (unsigned)((gn + (size_t)k * p.ldb) * 8);
             } else {
                 const int q = o >> 4;                       // 16-byte slot: (kp, n)
                 const int kp = q / BN, n = q - kp * BN;
                 int gn = n0 + n;
                 if (gn >= p.N) gn = 0;
-                src[s] = p.B + 2 * kp + (size_t)gn * p.ldb;
-                step[s] = BK;
+                voff[s] = (unsigned)((2 * kp + (size_t)gn * p.ldb) * 8);
             }
             loff[s] = Cfg::A_BYTES + cb * 1024;
         }
     }
+    const size_t stepA = (size_t)BK * p.lda * 8, stepB = BNMAJOR ? (size_t)BK * p.ldb * 8 : (size_t)BK * 8;
+    const char* sA = reinterpret_cast<const char*>(p.A);
+    const char* sB = reinterpret_cast<const char*>(p.B);
 
     auto issue = [&](int stage) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        char* base = lds + stage * Cfg::STAGE_BYTES;
+        const unsigned lbase = (unsigned)(size_t)(lds_ptr_t)lds + stage * Cfg::STAGE_BYTES;
 #pragma unroll
-        for (int s = 0; s < PER; ++s) {
-            __builtin_amdgcn_global_load_lds(src[s], (lds_ptr_t)(base + loff[s]), 16, 0, 0);
-            src[s] += step[s];
-        }
-#else
-        (void)stage;
-#endif
+        for (int s = 0; s < PER; ++s) lds_dma16(lbase + loff[s], voff[s], isA[s] ? sA : sB);
+        sA += stepA;
+        sB += stepB;
     };
 
     d4 acc[WTM][WTN];
@@ -195,7 +193,8 @@ static inline bool dl_applicable(int M, int N, int K, const double* A, int lda, 
                                  bool bnmajor)
 {
     return M >= 1 && N >= 1 && K >= 16 && (K & 15) == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
-           (lda & 1) == 0 && (ldb & 1) == 0 && lda >= M && (bnmajor ? ldb >= N : ldb >= K);
+           (lda & 1) == 0 && (ldb & 1) == 0 && lda >= M && (bnmajor ? ldb >= N : ldb >= K) &&
+           dma_offsets_fit((size_t)lda * 16 + M, bnmajor ? (size_t)ldb * 16 + N : (size_t)ldb * N + 16);
 }
 
 template <int WTM, int WTN, int WM, int WN, bool BNMAJOR, int STAGES, class Epi>

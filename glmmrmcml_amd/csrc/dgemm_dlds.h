@@ -42,6 +42,28 @@ constexpr int DL_BK = 16;     // K padding granule the callers provide (a multip
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// One LDS-DMA piece (1 KiB per wave: lane l's 16 bytes land at lds_addr + 16 l) in the SCALAR-BASE form:
+// address = sbase (uniform, advanced per K step by scalar adds) + voff (per-lane 32-bit byte offset that
+// never changes inside a K loop).  Hand-written: hipcc materialises base + offset into a 64-bit VGPR
+// temporary per load, and with per-lane 64-bit pointers advanced by VALU adds it may place an add right
+// behind the load that reads the same register -- that write-after-read stalls the wave until the load
+// has left the queue (measured on the banded kernel: 458 vs 419 us per launch).  The s_nop is the wait
+// state an LDS-DMA needs behind a SALU write of M0 (hipcc pads nothing inside asm).
+__device__ __forceinline__ void lds_dma16(unsigned lds_addr, unsigned voff, const void* sbase)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds_addr), "v"(voff), "s"(sbase) : "memory", "m0");
+#else
+    (void)lds_addr; (void)voff; (void)sbase;
+#endif
+}
+// per-lane byte offsets are 32-bit: the operands of one launch must span less than 4 GiB
+static inline bool dma_offsets_fit(size_t elems_a, size_t elems_b)
+{
+    return elems_a * 8 < 0xffffffffull && elems_b * 8 < 0xffffffffull;
+}
+
 template <int BK, int STAGES, class Epi>
 __global__ __launch_bounds__(512) void dgemm_dlds_kernel(GemmP p, Epi epi)
 {
@@ -226,7 +248,7 @@ __global__ __launch_bounds__(512) void dgemm_dlds_asm_kernel(GemmP p, Epi epi)
     const int bi = nid / p.gn, bj = nid - bi * p.gn;
     const int m0 = bi * DL_BM, n0 = bj * DL_BN;
 
-    const double* pa[Cfg::NA]; int la[Cfg::NA];
+    unsigned voa[Cfg::NA]; int la[Cfg::NA];
 #pragma unroll
     for (int s = 0; s < Cfg::NA; ++s) {
         int c = wave + 8 * s;
@@ -237,36 +259,30 @@ __global__ __launch_bounds__(512) void dgemm_dlds_asm_kernel(GemmP p, Epi epi)
         const int m = (((blk ^ (k & 1)) << 4) | within);
         int gm = m0 + m;
         if (gm >= p.M) gm = 0;
-        pa[s] = p.A + gm + (size_t)k * p.lda;
+        voa[s] = (unsigned)((gm + (size_t)k * p.lda) * 8);
         la[s] = c * 1024;
     }
-    const double* pb[Cfg::NB]; int lb[Cfg::NB];
+    unsigned vob[Cfg::NB]; int lb[Cfg::NB];
 #pragma unroll
     for (int s = 0; s < Cfg::NB; ++s) {
         const int c = wave + 8 * s;
         const int kp = c >> 1, n = ((c & 1) << 6) + lane;
         int gn = n0 + n;
         if (gn >= p.N) gn = 0;
-        pb[s] = p.B + 2 * kp + (size_t)gn * p.ldb;
+        vob[s] = (unsigned)((2 * kp + (size_t)gn * p.ldb) * 8);
         lb[s] = Cfg::A_BYTES + c * 1024;
     }
-    const size_t stepA = (size_t)BK * p.lda;
+    const size_t stepA = (size_t)BK * p.lda * 8;           // bytes per K step
+    const char* sA = reinterpret_cast<const char*>(p.A);   // uniform bases, advanced by scalar adds
+    const char* sB = reinterpret_cast<const char*>(p.B);
     auto issue = [&](int stage) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        char* base = lds + stage * Cfg::STAGE_BYTES;
+        const unsigned lbase = (unsigned)(size_t)(lds_ptr_t)lds + stage * Cfg::STAGE_BYTES;
 #pragma unroll
-        for (int s = 0; s < Cfg::NA; ++s) {
-            __builtin_amdgcn_global_load_lds(pa[s], (lds_ptr_t)(base + la[s]), 16, 0, 0);
-            pa[s] += stepA;
-        }
+        for (int s = 0; s < Cfg::NA; ++s) lds_dma16(lbase + la[s], voa[s], sA);
 #pragma unroll
-        for (int s = 0; s < Cfg::NB; ++s) {
-            __builtin_amdgcn_global_load_lds(pb[s], (lds_ptr_t)(base + lb[s]), 16, 0, 0);
-            pb[s] += BK;
-        }
-#else
-        (void)stage; (void)stepA;
-#endif
+        for (int s = 0; s < Cfg::NB; ++s) lds_dma16(lbase + lb[s], vob[s], sB);
+        sA += stepA;
+        sB += BK * 8;
     };
     auto wait_leave = [&](int tiles) {
         static_assert(Cfg::PER_TILE == 5, "vmcnt immediates below");
@@ -333,7 +349,8 @@ static inline bool dlds_applicable(int M, int N, int K, const double* A, int lda
 {
     const int kpad = round_up(K, 32);      // serves both K steps
     return M >= 1 && N >= 1 && K >= 1 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
-           (lda & 1) == 0 && (ldb & 1) == 0 && lda >= M && ldb >= kpad && a_cols_alloc >= kpad;
+           (lda & 1) == 0 && (ldb & 1) == 0 && lda >= M && ldb >= kpad && a_cols_alloc >= kpad &&
+           dma_offsets_fit((size_t)lda * 32 + M, (size_t)ldb * N + 32);
 }
 
 template <int BK, int STAGES, class Epi>

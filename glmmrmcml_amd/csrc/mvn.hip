@@ -201,33 +201,51 @@ __device__ __forceinline__ double rsqrt_nr(double x)
 }
 
 // One column of the 16 x 16 diagonal tile, branch-free (the 16 columns are one serial dependency
-// chain on a single wave: every exec-mask branch in it costs a pipeline bubble).  `bad`
-// accumulates failed pivots, `yv` collects lane r's reciprocal pivot 1 / L_rr.
+// chain on a single wave: every exec-mask branch in it costs a pipeline bubble).  Lane `ln` holds one
+// ROW of the 16 columns being eliminated: lanes 0-15 are the tile's own rows (lane C is the pivot row of
+// column C), lanes >= 16 are rows that ride along (x L11' = a for any row a costs no extra instruction on
+// a 64-lane wave).  `bad` accumulates failed pivots, `yv` collects lane C's reciprocal pivot 1 / L_CC.
 template <int C>
-__device__ __forceinline__ void potrf16_col(double (&a)[16], int r, int& bad, double& yv)
+__device__ __forceinline__ void potrf16_col(double (&a)[16], int ln, int& bad, double& yv)
 {
     double diag = bcast_lane<C>(a[C]);
     const bool ok = diag > 0.0;
     bad |= ok ? 0 : 1;
     diag = ok ? diag : 1.0;
     const double y = rsqrt_nr(diag);
-    double d = diag * y;                                   // sqrt(diag), one correction step
-    d = __builtin_fma(__builtin_fma(-d, d, diag), 0.5 * y, d);
-    const double l = (r == C) ? d : a[C] * y;
-    yv = (r == C) ? y : yv;
+    // every row, the pivot row included, is scaled by the reciprocal pivot: L_CC = diag * rsqrt(diag) is sqrt(diag) to
+    // ~1.5 ulp (no separate square root, no lane-dependent branch on the serial chain)
+    const double l = a[C] * y;
+    yv = (ln == C) ? y : yv;
     a[C] = l;
     if constexpr (C < 15) {
         // a[j] -= l * l_j for j > C, l_j = lane j's l
-        potrf16_upd<C, C + 1>(a, l, r);
+        potrf16_upd<C, C + 1>(a, l, ln);
     }
 }
 
-// Leaf of the recursive factorisation: n <= 128.  One workgroup keeps the
-// block in LDS (row stride 129: conflict-free column walks), factorises it in
-// 16-wide panels (the 16x16 diagonal tile in registers via wave shuffles), then
-// inverts the factor in place into the unused upper triangle.  Writes L over
-// the lower triangle of A and inv(L) to Linv (128 x 128, ld 128, upper zeroed).
-constexpr int LEAF_NT = 512, LEAF_NW = LEAF_NT / 64;      // 8 waves: the panel / trailing / inverse phases are wave-parallel
+// Leaf of the blocked factorisation: n <= 128.  One workgroup keeps the block in LDS (row stride 129:
+// conflict-free column walks) and factorises it in 16-wide steps; the unused upper triangle receives the
+// inverse X = inv(L) (X[i][j], i > j, at S[j][i]; its diagonal = the reciprocal pivots, in xd).  Writes L over
+// the lower triangle of A and inv(L) to Linv (128 x 128, ld 128; the caller has zeroed it: entries above the
+// diagonal and beyond n are never written).
+//
+// Step kt (columns kb = 16 kt ...) is software-pipelined so that the serial part is as short as possible:
+//   P1  wave 0: the 16 x 16 diagonal tile in registers, one row per lane, readlane broadcasts.  Lanes 16-31
+//       carry the 16 rows of the identity (their solution is X_II, the diagonal tile of the inverse) and lanes
+//       32-63 the first 32 rows of the panel below -- on a 64-lane wave those rows cost nothing.
+//       waves 1-7 meanwhile: the trailing-update tiles of step kt-1 that wave 0 did not need, then block row
+//       kt-1 of the inverse (MFMA), stored straight to Linv.
+//   P2  all waves: the rest of the panel, rows x X_II' on the matrix cores (4 MFMAs per 16 rows).
+//   P3  wave 0: the three trailing tiles the next step's P1 reads (next diagonal tile + its 32 ride-along
+//       rows), then straight into P1 of step kt+1 with no workgroup barrier in between.
+constexpr int LEAF_NT = 512, LEAF_NW = LEAF_NT / 64;
+// workgroup barrier for LDS traffic only.  __syncthreads() also waits for vmcnt(0): with Linv stored to global
+// memory as the leaf goes, every barrier would wait for those stores to be acknowledged (~1-2 us each).
+__device__ __forceinline__ void leaf_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __global__ __launch_bounds__(LEAF_NT) void k_potrf_leaf(double* A, int lda, int n, double* Linv, int* errflag,
                                                     unsigned long long* prof)
 {
@@ -237,6 +255,7 @@ __global__ __launch_bounds__(LEAF_NT) void k_potrf_leaf(double* A, int lda, int 
     extern __shared__ __attribute__((aligned(16))) double S[];
     constexpr int LS = 129;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lk = lane >> 4;
     {   // load the lower triangle: thread = (row, column parity); 16 loads in flight per thread
         constexpr int JG = LEAF_NT / 128;
         const int i = tid & 127, j0 = tid >> 7;
@@ -253,21 +272,15 @@ __global__ __launch_bounds__(LEAF_NT) void k_potrf_leaf(double* A, int lda, int 
     }
     __syncthreads();
     LEAF_T(1);
-    unsigned long long ta = 0, tb = 0, tc = 0, t_;
+    unsigned long long ta = 0, tb = 0, tc = 0, t_, q0 = 0, q1 = 0, q2 = 0, q3 = 0, u_;
     const int ntile = (n + 15) >> 4;
-    // ---- inverse X = inv(L), 16 x 16 tiles; X[i][j] (i > j) is kept at S[j][i] (the unused upper
-    // triangle), its diagonal (= the reciprocal pivots phase (a) stores) in xd.  Block row I is
-    // complete once tile (I, I) is factorised, so waves 1..7 compute row I of the inverse while
-    // wave 0 runs the serial phase (a) of step I + 1: off the critical path.  Wave w owns column
-    // tile J = w - 1 and keeps its T_J in a private scratch tile -- no barrier is needed inside
-    // the row.  The diagonal tiles X_II cost nothing: phase (b) solves x L11' = e_j for the 16
-    // rows of the identity along with the panel rows, which is X_II' written straight into the
-    // upper part of the diagonal tile.
-    double* xd = S + 128 * LS;            // 128 doubles
-    double* Tt = xd + 128;                // 7 tiles of 16 x 16
+    double* xd = S + 128 * LS;            // 128 doubles: reciprocal pivots = diagonal of the inverse
+    double* Tt = xd + 128;                // 7 scratch tiles of 16 x 16 (one per wave 1..7)
+    double* dummy = Tt + 7 * 256;         // 64 doubles nobody reads (address-select stores)
+
+    // block row I of the inverse (waves 1..7: wave w owns column tile J = w - 1)
     auto inverse_row = [&](int I) {
         const int J = wave - 1;
-        const int l15 = lane & 15, lk = lane >> 4;
         if (J >= I) return;
         // T_J = sum_{K=J}^{I-1} L_IK X_KJ on the matrix cores
         d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -300,89 +313,143 @@ __global__ __launch_bounds__(LEAF_NT) void k_potrf_leaf(double* A, int lda, int 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gi = I * 16 + lk + 4 * r, gj = J * 16 + l15;
-            if (gi < n) S[gj * LS + gi] = -acc2[r];
+            if (gi < n) {
+                S[gj * LS + gi] = -acc2[r];
+                Linv[gi + gj * 128] = -acc2[r];
+            }
         }
     };
+    // trailing tile (ti, tj) -= P_ti P_tj' with the panel of step kb (K = 16), on the matrix cores
+    auto upd_tile = [&](int ti, int tj, int kb) {
+        const int ri = ti * 16, rj = tj * 16;
+        d4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = S[(ri + lk + 4 * r) * LS + rj + l15];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const double pa = -S[(ri + l15) * LS + kb + kc * 4 + lk];
+            const double pb = S[(rj + l15) * LS + kb + kc * 4 + lk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(ri + lk + 4 * r) * LS + rj + l15] = acc[r];
+    };
+    // the tiles of step kt's trailing update that wave 0 does NOT do itself, shared out over waves 1..7
+    auto rest_update = [&](int kt) {
+        int cnt = 0;
+        for (int tj = kt + 1; tj < ntile; ++tj)
+            for (int ti = tj; ti < ntile; ++ti) {
+                if (tj == kt + 1 && ti <= kt + 3) continue;            // wave 0's (P3)
+                if (cnt % (LEAF_NW - 1) == wave - 1) upd_tile(ti, tj, kt * 16);
+                ++cnt;
+            }
+    };
+
     for (int kt = 0; kt < ntile; ++kt) {
         const int kb = kt * 16;
         t_ = __builtin_amdgcn_s_memtime();
         if (wave == 0) {
-            // (a) 16x16 diagonal tile, one row per lane (lanes >= 16 mirror lane&15)
-            const int r = lane & 15;
-            int bad = 0; double yv = 1.0;                  // failed pivots; this lane's reciprocal pivot
+            // P1: lane < 16 tile row kb + lane; 16..31 identity row lane - 16; 32..63 panel row kb + 16 + (lane - 32)
+            const int prow = kb + 16 + (lane - 32);
+            const bool pvalid = lane >= 32 && prow < ntile * 16;
+            int bad = 0; double yv = 1.0;
             double a[16];
+            u_ = __builtin_amdgcn_s_memtime();
+            // branch-free: one load per column from a clamped, always valid row; selects supply the identity
+            // (padding rows of the tile, lanes 16-31) and zeros (padding rows of the panel)
+            const int lrow = lane < 32 ? kb + l15 : (pvalid ? prow : 0);
+            const bool ld_row = lane < 16 ? (kb + lane < n) : pvalid;
+            const double* srow = S + lrow * LS + kb;
 #pragma unroll
-            for (int c = 0; c < 16; ++c)
-                a[c] = (kb + r < n && kb + c < n) ? S[(kb + r) * LS + kb + c] : (r == c ? 1.0 : 0.0);
-            potrf16_col<0>(a, r, bad, yv);  potrf16_col<1>(a, r, bad, yv);
-            potrf16_col<2>(a, r, bad, yv);  potrf16_col<3>(a, r, bad, yv);
-            potrf16_col<4>(a, r, bad, yv);  potrf16_col<5>(a, r, bad, yv);
-            potrf16_col<6>(a, r, bad, yv);  potrf16_col<7>(a, r, bad, yv);
-            potrf16_col<8>(a, r, bad, yv);  potrf16_col<9>(a, r, bad, yv);
-            potrf16_col<10>(a, r, bad, yv); potrf16_col<11>(a, r, bad, yv);
-            potrf16_col<12>(a, r, bad, yv); potrf16_col<13>(a, r, bad, yv);
-            potrf16_col<14>(a, r, bad, yv); potrf16_col<15>(a, r, bad, yv);
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    if (r >= c && kb + r < n && kb + c < n) S[(kb + r) * LS + kb + c] = a[c];
-                S[128 * LS + kb + r] = yv;                 // reciprocal diagonal = the inverse's diagonal (xd)
-                if (bad && lane == 0) atomicExch(errflag, 1);
+            for (int c = 0; c < 16; ++c) {
+                const double v = srow[c];
+                const bool use = ld_row && (lane >= 32 || kb + c < n);
+                a[c] = use ? v : ((lane < 32 && l15 == c) ? 1.0 : 0.0);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            q0 += __builtin_amdgcn_s_memtime() - u_; u_ = __builtin_amdgcn_s_memtime();
+            potrf16_col<0>(a, lane, bad, yv);  potrf16_col<1>(a, lane, bad, yv);
+            potrf16_col<2>(a, lane, bad, yv);  potrf16_col<3>(a, lane, bad, yv);
+            potrf16_col<4>(a, lane, bad, yv);  potrf16_col<5>(a, lane, bad, yv);
+            potrf16_col<6>(a, lane, bad, yv);  potrf16_col<7>(a, lane, bad, yv);
+            potrf16_col<8>(a, lane, bad, yv);  potrf16_col<9>(a, lane, bad, yv);
+            potrf16_col<10>(a, lane, bad, yv); potrf16_col<11>(a, lane, bad, yv);
+            potrf16_col<12>(a, lane, bad, yv); potrf16_col<13>(a, lane, bad, yv);
+            potrf16_col<14>(a, lane, bad, yv); potrf16_col<15>(a, lane, bad, yv);
+            q1 += __builtin_amdgcn_s_memtime() - u_; u_ = __builtin_amdgcn_s_memtime();
+            // lanes 0-15 write row kb + l15 up to the diagonal (L), lanes 16-31 the SAME row above it (x[c] =
+            // X_II[c][jj], c > jj: kept in the tile's upper part for the MFMA phases), lanes 32-63 their panel row.
+            // Full leaves (n = 128) store through ADDRESS selects (a lane with nothing to store hits a dummy slot):
+            // per-column exec masks cost this wave ~100 SGPRs, which spill, and the serial chain pays the reloads.
+            double* drow = S + lrow * LS + kb;
+            if (n == 128) {
+                double* dmy = dummy + lane;
+                double* w1 = (lane < 16 || pvalid) ? drow : nullptr;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) *(w1 ? w1 + c : dmy) = a[c];          // rows, all 16 columns
+                // then (LDS keeps a wave's accesses in order) the identity lanes overwrite the part above the diagonal
+#pragma unroll
+                for (int c = 0; c < 16; ++c) *((lk == 1 && c > l15) ? drow + c : dmy) = a[c];
+                if (lane < 16) xd[kb + lane] = yv;         // reciprocal diagonal = the inverse's diagonal
+                if (lk == 1) {
+                    // the diagonal tile of the inverse is final: x[c] = X_II[c][jj] for c >= jj, exact zeros above
+                    double* g = Linv + (kb + l15) * 128 + kb;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) g[c] = a[c];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const bool st = lane < 16 ? (l15 >= c && kb + l15 < n && kb + c < n) : (lane < 32 ? c > l15 : pvalid);
+                    if (st) drow[c] = a[c];
+                }
+                if (lane < 16) xd[kb + lane] = yv;
+                if (lk == 1) {
+                    double* g = Linv + (kb + l15) * 128 + kb;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        if (c >= l15 && kb + c < n && kb + l15 < n) g[c] = a[c];
+                }
+            }
+            if (bad && lane == 0) atomicExch(errflag, 1);
+            q2 += __builtin_amdgcn_s_memtime() - u_; u_ = __builtin_amdgcn_s_memtime();
         } else if (kt >= 1) {
+            rest_update(kt - 1);
             inverse_row(kt - 1);
         }
-        __syncthreads();
+        leaf_sync();
+        q3 += __builtin_amdgcn_s_memtime() - u_;
         ta += __builtin_amdgcn_s_memtime() - t_; t_ = __builtin_amdgcn_s_memtime();
-        // (b) panel below the tile: x L11^T = a, one row per thread (rows padded to the tile grid
-        // are zero and stay zero).  The tile's own 16 rows ride along with right-hand side e_j:
-        // their solution is row j of inv(L11)', i.e. X_II, stored in the tile's upper part.
-        // Right-looking substitution: once x[k] is known every later column's partial sum is updated
-        // at once, so the 120 multiply-adds of a row pipeline instead of forming 16 long chains.
-        {
-            const bool ident = wave == LEAF_NW - 1;        // the last wave: lanes 0-15 = the identity rows
-            const int jj = lane;
-            const int i = ident ? kb + jj : kb + 16 + tid;
-            if (ident ? (lane < 16) : (i < ntile * 16)) {
-                double sv[16], x[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) sv[c] = ident ? (c == jj ? 1.0 : 0.0) : S[i * LS + kb + c];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    x[k] = (kb + k < n) ? sv[k] * S[128 * LS + kb + k] : 0.0;
-#pragma unroll
-                    for (int c = k + 1; c < 16; ++c) sv[c] -= x[k] * S[(kb + c) * LS + kb + k];
-                }
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    if (!ident || c > jj) S[i * LS + kb + c] = x[c];
-            }
-        }
-        __syncthreads();
-        tb += __builtin_amdgcn_s_memtime() - t_; t_ = __builtin_amdgcn_s_memtime();
-        // (c) trailing update of the lower tiles on the matrix cores: C -= P P^T, K = 16
-        const int t0 = kt + 1, nrem = ntile - t0;
-        const int ntri = nrem * (nrem + 1) / 2;
-        for (int t = wave; t < ntri; t += LEAF_NW) {
-            int ti = 0, rem = t;                       // t -> (ti >= tj) in row-major triangle order
-            while (rem > ti) { rem -= ti + 1; ++ti; }
-            const int tj = rem;
-            const int ri = (t0 + ti) * 16, rj = (t0 + tj) * 16;
-            d4 acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = S[(ri + (lane >> 4) + 4 * r) * LS + rj + (lane & 15)];
+        // P2: panel rows beyond the 32 that rode along: x = a inv(L11)' = a X_II' on the matrix cores
+        for (int t = kt + 3 + wave; t < ntile; t += LEAF_NW) {
+            const int r0 = t * 16;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            double pa[4], pb[4];
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
-                const double pa = -S[(ri + (lane & 15)) * LS + kb + kc * 4 + (lane >> 4)];
-                const double pb = S[(rj + (lane & 15)) * LS + kb + kc * 4 + (lane >> 4)];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
+                const int k = kc * 4 + lk;
+                pa[kc] = S[(r0 + l15) * LS + kb + k];                      // a[i = l15][k]
+                // B[k][j = l15] = X_II[j][k]
+                pb[kc] = (l15 == k) ? xd[kb + k] : (l15 > k ? S[(kb + k) * LS + kb + l15] : 0.0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) S[(ri + (lane >> 4) + 4 * r) * LS + rj + (lane & 15)] = acc[r];
+            for (int kc = 0; kc < 4; ++kc) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[kc], pb[kc], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(r0 + lk + 4 * r) * LS + kb + l15] = acc[r];
         }
-        __syncthreads();
+        leaf_sync();
+        tb += __builtin_amdgcn_s_memtime() - t_; t_ = __builtin_amdgcn_s_memtime();
+        // P3: wave 0 updates what its next P1 reads and goes on without a barrier; the other waves pick up the
+        // rest of this step's trailing update at the top of the next iteration
+        if (wave == 0) {
+            for (int ti = kt + 1; ti < ntile && ti <= kt + 3; ++ti) upd_tile(ti, kt + 1, kb);
+            // the next P1 reads, one row per lane, what other lanes of this wave have just written: LDS executes a
+            // wave's accesses in order; this keeps the compiler from moving them
+            asm volatile("" ::: "memory");
+        }
         tc += __builtin_amdgcn_s_memtime() - t_;
     }
+    leaf_sync();
     if (prof && threadIdx.x == 0) { prof[2] = ta; prof[3] = tb; prof[4] = tc; }
     LEAF_T(5);
     {   // write L
@@ -390,22 +457,11 @@ __global__ __launch_bounds__(LEAF_NT) void k_potrf_leaf(double* A, int lda, int 
         if (i < n)
             for (int j = j0; j <= i && j < n; j += LEAF_NT / 128) A[i + (size_t)j * lda] = S[i * LS + j];
     }
-    // the last block row of the inverse (the earlier ones were done under the later steps' phase (a))
     LEAF_T(6);
+    // the last block row of the inverse (the earlier ones were done under the later steps' P1)
     if (wave >= 1) inverse_row(ntile - 1);
-    __syncthreads();
-    LEAF_T(7);
-    LEAF_T(8);
-    for (int e = tid; e < 128 * 128; e += LEAF_NT) {
-        int i = e & 127, j = e >> 7;
-        double v = 0.0;
-        if (i < n && j < n) {
-            if (i == j) v = xd[j];
-            else if (i > j) v = S[j * LS + i];
-        }
-        Linv[i + j * 128] = v;
-    }
     LEAF_T(9);
+    if (prof && threadIdx.x == 0) { prof[6] = q0; prof[7] = q1; prof[8] = q2; prof[1] = q3; }
 #undef LEAF_T
 }
 
@@ -419,10 +475,11 @@ int potrf_leaf_profile(Ctx& c, unsigned long long* host10)
     std::vector<double> h((size_t)A.ld * 128, 0.0);
     for (int j = 0; j < 128; ++j) for (int i = 0; i < 128; ++i) h[i + (size_t)j * A.ld] = (i == j ? 130.0 : 1.0 / (1 + abs(i - j)));
     MCML_HIP(hipMemcpy(A.d(), h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
-    MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_potrf_leaf), (int)(sizeof(double) * (128 * 129 + 128 + 7 * 256))));
+    MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_potrf_leaf), (int)(sizeof(double) * (128 * 129 + 128 + 7 * 256 + 64))));
+    MCML_HIP(hipMemset(c.linv.p, 0, sizeof(double) * 2 * CHOL_NB * CHOL_NB));
     for (int rep = 0; rep < 3; ++rep) {
         MCML_HIP(hipMemcpy(A.d(), h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(LEAF_NT), sizeof(double) * (128 * 129 + 128 + 7 * 256), c.stream, A.d(), A.ld,
+        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(LEAF_NT), sizeof(double) * (128 * 129 + 128 + 7 * 256 + 64), c.stream, A.d(), A.ld,
                            128, c.linv.d(), c.scalars.as<int>() + 32, prof.as<unsigned long long>());
         MCML_HIP(hipStreamSynchronize(c.stream));
     }
@@ -475,7 +532,7 @@ __global__ void k_zero_upper(double* A, int lda, int n)
 }
 
 // LDS of k_potrf_leaf: the 128 x 129 block, the inverse's diagonal, 7 scratch tiles
-static constexpr size_t POTRF_LDS = sizeof(double) * (128 * 129 + 128 + 7 * 256);
+static constexpr size_t POTRF_LDS = sizeof(double) * (128 * 129 + 128 + 7 * 256 + 64);
 
 // ------------------------------------------------------------------ recursion (host)
 static inline int split128(int n)
@@ -645,6 +702,8 @@ int potrf_lower(Ctx& c, double* A, int n, int lda)
 {
     MCML_REQUIRE(n > 0 && lda >= n && (lda & 1) == 0, "potrf: bad shape n=%d lda=%d", n, lda);
     MCML_TRY(c.linv.ensure(sizeof(double) * (size_t)(n / CHOL_NB + 1) * CHOL_NB * CHOL_NB));
+    // the leaves write the lower triangles of their inverses only (k_potrf_leaf)
+    MCML_HIP(hipMemsetAsync(c.linv.p, 0, sizeof(double) * (size_t)((n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB, c.stream));
     MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_potrf_leaf), (int)POTRF_LDS));
     if (chol_blocked()) return potrf_blocked(c, A, lda, n);
     return potrf_rec(c, A, lda, 0, n);

@@ -9,11 +9,5 @@ _lib.check(_lib.lib().glmmr_mcml_dbg_leaf_profile(ctx._h, out))
 t = [int(x) for x in out]
 names = ["load", None, None, None, None, "write L", "inv diag", "inv rows", "write Linv"]
 print("total cycles", t[9] - t[0], "= %.1f us at 2.4 GHz" % ((t[9] - t[0]) / 2400.0))
-print("load          ", t[1] - t[0])
-print("(a) diag tiles ", t[2])
-print("(b) panel solve", t[3])
-print("(c) trailing   ", t[4])
-print("factor total   ", t[5] - t[1])
-print("write L        ", t[6] - t[5])
-print("last inverse row", t[7] - t[6], " (rows 0..6 run under phase (a) of the following step)")
-print("write Linv     ", t[9] - t[8])
+print("(P1+sync) total ", t[2], " P2", t[3], " P3 (wave 0)", t[4])
+print("P1 wave 0: loads", t[6], " chain", t[7], " stores", t[8], " wait at sync", t[1])

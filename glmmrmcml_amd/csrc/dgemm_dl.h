@@ -79,13 +79,28 @@ __global__ __launch_bounds__(64 * WM * WN) void dgemm_dl_kernel(GemmP p, Epi epi
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave - wr * WN;
 
-    const int nblk = p.gm * p.gn;
+    const int nblk = gridDim.x;
     const int bid = blockIdx.x;
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
     const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int bi = nid / p.gn, bj = nid - bi * p.gn;
+    int bi, bj;
+    if (p.lower_only) {
+        // only the tiles that touch the lower triangle were launched (dl_lower_tiles): row band bi holds
+        // its first min(gn, last column tile under the diagonal + 1) column tiles; a short scalar walk finds
+        // (bi, bj).  Every XCD gets the same number of working tiles (the plain map gave the XCD of the
+        // bottom rows twice the average).
+        int rem = nid;
+        for (bi = 0; bi < p.gm; ++bi) {
+            int nc = (bi * BM + BM - 1 + p.diag_shift) / BN + 1;
+            if (nc > p.gn) nc = p.gn;
+            if (rem < nc) break;
+            rem -= nc;
+        }
+        bj = rem;
+    } else {
+        bi = nid / p.gn; bj = nid - bi * p.gn;
+    }
     const int m0 = bi * BM, n0 = bj * BN;
-    if (p.lower_only && n0 >= m0 + BM) return;             // whole workgroup, before any barrier
 
     // ---- this wave's LDS-DMA pieces: a uniform base per operand (advanced per K step by scalar adds) plus a
     // per-lane 32-bit byte offset that never changes (lds_dma16, dgemm_dlds.h); piece s of a wave belongs to A
@@ -203,8 +218,16 @@ static inline int launch_gemm_dl_cfg(hipStream_t s, GemmP p, const Epi& epi)
     using Cfg = DlgCfg<WTM, WTN, WM, WN, BNMAJOR, STAGES>;
     p.gm = (p.M + Cfg::BM - 1) / Cfg::BM;
     p.gn = (p.N + Cfg::BN - 1) / Cfg::BN;
+    long ntiles = (long)p.gm * p.gn;
+    if (p.lower_only) {
+        ntiles = 0;
+        for (int bi = 0; bi < p.gm; ++bi) {
+            int nc = (bi * Cfg::BM + Cfg::BM - 1 + p.diag_shift) / Cfg::BN + 1;
+            ntiles += nc > p.gn ? p.gn : nc;
+        }
+    }
     MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&dgemm_dl_kernel<WTM, WTN, WM, WN, BNMAJOR, STAGES, Epi>), (int)Cfg::LDS_BYTES));
-    hipLaunchKernelGGL((dgemm_dl_kernel<WTM, WTN, WM, WN, BNMAJOR, STAGES, Epi>), dim3(p.gm * p.gn),
+    hipLaunchKernelGGL((dgemm_dl_kernel<WTM, WTN, WM, WN, BNMAJOR, STAGES, Epi>), dim3((unsigned)ntiles),
                        dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, p, epi);
     MCML_HIP(hipGetLastError());
     return MCML_OK;
@@ -215,16 +238,17 @@ static inline int launch_gemm_dl_cfg(hipStream_t s, GemmP p, const Epi& epi)
 // 4 = 128 x 128 with a 2-stage ring (64 KB) and 5 = 64 x 128 with 3 stages (72 KB): TWO workgroups per
 // CU, so one's prologue / epilogue overlaps the other's MFMA work and the tile count quantises over 512
 // slots -- measured best for every K = 128 update of the Q = 5000 factorisation;  6 = 64 x 64, 4 waves,
-// 48 KB (three per CU).
+// 48 KB (three per CU);  7 = 16 x 128 and 8 = 32 x 32, 4 waves: the single-block products on the
+// factorisation's critical path (one 128 x 128 x 128 product spread over 8 / 16 CUs).
 // inplace: 0 none; 1 = C aliases A (needs BN >= N); 2 = C aliases B (needs BM >= M).
 template <bool BNMAJOR, class Epi>
 static inline int launch_gemm_dl(hipStream_t s, int M, int N, int K, const double* A, int lda,
                                  const double* B, int ldb, const Epi& epi, bool lower_only = false, int tile = 0,
-                                 int inplace = 0)
+                                 int inplace = 0, int diag_shift = 0)
 {
     MCML_REQUIRE(dl_applicable(M, N, K, A, lda, B, ldb, BNMAJOR), "dgemm_dl: shape/alignment contract violated "
                  "(M %d N %d K %d lda %d ldb %d)", M, N, K, lda, ldb);
-    GemmP p{M, N, K, A, lda, B, ldb, 0, 0, lower_only ? 1 : 0, 0};
+    GemmP p{M, N, K, A, lda, B, ldb, 0, 0, lower_only ? 1 : 0, 0, diag_shift};
     if (tile == 0) {
         long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
         if (lower_only) t128 = t128 / 2 + (M + 127) / 128;
@@ -236,13 +260,16 @@ static inline int launch_gemm_dl(hipStream_t s, int M, int N, int K, const doubl
         if (inplace == 0 && t128 < thr64) tile = 6;
         if (inplace == 2) tile = N >= 256 ? 3 : 1;
     }
-    MCML_REQUIRE(!(inplace == 1 && tile == 6 && N > 64) && !(inplace == 2 && (tile == 2 || tile == 5 || tile == 6) && M > 64),
+    MCML_REQUIRE(!(inplace == 1 && (tile == 6 || tile == 8) && N > (tile == 6 ? 64 : 32)) &&
+                 !(inplace == 2 && (tile == 2 || tile == 5 || tile == 6 || tile == 7 || tile == 8) && M > (tile == 7 ? 16 : tile == 8 ? 32 : 64)),
                  "dgemm_dl: tile %d cannot run this product in place", tile);
     if (tile == 1) return launch_gemm_dl_cfg<4, 2, 2, 4, BNMAJOR, 4, Epi>(s, p, epi);
     if (tile == 3) return launch_gemm_dl_cfg<1, 2, 8, 1, BNMAJOR, 6, Epi>(s, p, epi);
     if (tile == 4) return launch_gemm_dl_cfg<4, 2, 2, 4, BNMAJOR, 2, Epi>(s, p, epi);
     if (tile == 5) return launch_gemm_dl_cfg<2, 2, 2, 4, BNMAJOR, 3, Epi>(s, p, epi);
     if (tile == 6) return launch_gemm_dl_cfg<2, 2, 2, 2, BNMAJOR, 3, Epi>(s, p, epi);
+    if (tile == 7) return launch_gemm_dl_cfg<1, 2, 1, 4, BNMAJOR, 4, Epi>(s, p, epi);    // 16 x 128, 4 waves
+    if (tile == 8) return launch_gemm_dl_cfg<1, 1, 2, 2, BNMAJOR, 4, Epi>(s, p, epi);    // 32 x 32, 4 waves
     return launch_gemm_dl_cfg<2, 2, 2, 4, BNMAJOR, 5, Epi>(s, p, epi);
 }
 

@@ -41,6 +41,7 @@ struct GemmP {
     int gm, gn;                 // tile grid
     int lower_only;             // skip tiles that lie strictly above the diagonal
     int dbg_nostep;             // timing experiment only: do not advance the operand pointers
+    int diag_shift = 0;         // dgemm_dl lower_only: row m of C is row m + diag_shift of the square matrix
 };
 
 // WTM x WTN: 16x16 MFMA tiles per wave; WM x WN: waves per workgroup.

@@ -153,13 +153,17 @@ __global__ __launch_bounds__(64) void k_small_ll(const double* U, int ldu, int m
 
 // ------------------------------------------------------------------ large blocks
 // lower triangle (mirrored) of one block's covariance matrix
+// (dpad > dim: rows / columns dim .. dpad are an identity border, so that an odd block can be factorised as an
+// even one -- every panel pointer stays 16-byte aligned; the border does not change L, the log-determinant or
+// the solves)
 __global__ __launch_bounds__(256) void k_build_dense(double* A, int lda, int bidx, const CovBlock* blocks,
                                                      const int32_t* cov, int rows, const double* data,
-                                                     ThetaArg th, int mirror)
+                                                     ThetaArg th, int mirror, int dpad)
 {
     if (blockIdx.x < blockIdx.y) return;
     const CovBlock blk = blocks[bidx];
     const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= blk.dim && i < dpad && j <= i) { A[i + (size_t)j * lda] = (i == j) ? 1.0 : 0.0; return; }
     if (i >= blk.dim || j >= blk.dim || i < j) return;
     double v = cov_entry(blk, cov, rows, data + blk.doff, th, i, j);
     A[i + (size_t)j * lda] = v;
@@ -487,6 +491,23 @@ int potrf_leaf_profile(Ctx& c, unsigned long long* host10)
     return MCML_OK;
 }
 
+// AT (cols x rows) = A' through a 32 x 33 LDS tile
+__global__ __launch_bounds__(256) void k_transpose_in(const double* A, int lda, int rows, int cols, double* AT, int ldt)
+{
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int i = bx + tx, j = by + r;
+        tile[r][tx] = (i < rows && j < cols) ? A[i + (size_t)j * lda] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int j = by + tx, i = bx + r;
+        if (i < rows && j < cols) AT[j + (size_t)i * ldt] = tile[tx][r];
+    }
+}
+
 __global__ void k_copy_block(double* dst, int ldd, const double* src, int lds, int rows, int cols)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -627,55 +648,76 @@ static int lookahead_setup(Ctx& c)
     return MCML_OK;
 }
 
-static int potrf_blocked(Ctx& c, double* A, int lda, int n)
+// Right-looking blocked Cholesky of the n x n lower triangle of A, 128-wide panels, with `extra` more ROWS
+// carried below the matrix (rows n .. n+extra of the same column-major array): they receive every panel
+// operation the rows of the matrix receive, i.e. X <- X inv(L)'.  With X = U' (the sample columns, one per
+// extra row) that is the forward substitution inv(L) U of mvn_ll, done inside the factorisation's own GEMMs
+// -- no separate TRSM pass, and the late panels, whose trailing matrices are tiny, still fill the chip.
+//
+// Step t, on the main stream: the ONE 128 x 128 panel block that becomes the next diagonal block's multiplier
+// and that block's own update (two single-block products spread over 8 / 16 CUs); then, forked to a
+// high-priority side stream, leaf(t+1) -- while the main stream runs the bulk: the rest of panel t and the
+// whole trailing update except that block, one launch, lower tiles only, balanced over the XCDs.  The leaf
+// (ONE workgroup that needs a whole CU's LDS) becomes ready together with the bulk and is dispatched first, so
+// it never waits for a CU to drain.  The main stream joins the leaf before step t+1.  Period: two small GEMMs
+// + max(bulk, leaf).  (A freer two-queue schedule with the bulk on a CU-masked stream measured ~10 % faster
+// but hung intermittently in cross-stream waits; this fork-join is the round-1 pattern, which never did.)
+//   GLMMR_MCML_CHOL=rec : the recursive variant;  =nola : everything on one stream
+static int potrf_blocked(Ctx& c, double* A, int lda, int n, int extra)
 {
-    // look-ahead pays while the rest of the trailing update is at least as long as a leaf
-    static const int la_min = getenv("GLMMR_MCML_LA_MIN") ? atoi(getenv("GLMMR_MCML_LA_MIN")) : 1536;
-    const bool la_any = chol_mode() == 1 && n - 2 * CHOL_NB >= la_min;
-    if (la_any) MCML_TRY(lookahead_setup(c));
     int* errflag = c.scalars.as<int>() + 32;
+    const bool two = chol_mode() == 1 && n > 2 * CHOL_NB;
+    hipStream_t sM = c.stream, sL = c.stream;
+    if (two) { MCML_TRY(lookahead_setup(c)); sL = c.aux; }
     auto leaf = [&](hipStream_t s, int k, int nb) -> int {
         hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(LEAF_NT), POTRF_LDS, s, A + k + (size_t)k * lda, lda, nb,
                            c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB, errflag, nullptr);
         MCML_HIP(hipGetLastError());
         return MCML_OK;
     };
-    MCML_TRY(leaf(c.stream, 0, n < CHOL_NB ? n : CHOL_NB));
-    for (int k = 0; k < n; k += CHOL_NB) {
+    // C (M x N) = alpha A B' + beta C with B N-major, preferring the LDS-DMA kernel with a given tile
+    auto gemm_nt = [&](int M, int N, int K, const double* Ap, const double* Bp, int ldb, double* Cp,
+                       double alpha, double beta, bool lower, int tile, int inplace, int shift) -> int {
+        EpiAxpby epi{Cp, lda, alpha, beta};
+        if (dl_applicable(M, N, K, Ap, lda, Bp, ldb, true))
+            return launch_gemm_dl<true>(sM, M, N, K, Ap, lda, Bp, ldb, epi, lower, tile, inplace, shift);
+        MCML_REQUIRE(shift == 0 || !lower, "potrf: shifted lower-only update needs the LDS-DMA kernel");
+        return launch_gemm<true>(sM, M, N, K, Ap, lda, Bp, ldb, epi, lower, inplace ? inplace : -1);
+    };
+    const int nsteps = (n + CHOL_NB - 1) / CHOL_NB;
+    MCML_TRY(leaf(sM, 0, n < CHOL_NB ? n : CHOL_NB));
+    bool forked = false;
+    for (int t = 0; t < nsteps; ++t) {
+        const int k = t * CHOL_NB;
         const int nb = (n - k < CHOL_NB) ? n - k : CHOL_NB;
         double* A11 = A + k + (size_t)k * lda;
-        const double* Linv = c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB;
-        const int rem = n - k - nb;
-        if (rem <= 0) break;
-        double* A21 = A11 + nb;
-        {
-            EpiAxpby epi{A21, lda, 1.0, 0.0};
-            MCML_TRY(chol_gemm<true>(c.stream, rem, nb, nb, A21, lda, Linv, CHOL_NB, epi, false, 1));
+        const double* Linv = c.linv.d() + (size_t)t * CHOL_NB * CHOL_NB;
+        const int rem = n - k - nb, R = rem + extra;
+        if (R <= 0) break;
+        double* A21 = A11 + nb;                                   // R x nb: the panel below the diagonal block
+        const int nb2 = rem < CHOL_NB ? rem : CHOL_NB;            // rows of the next diagonal block (0 at the end)
+        if (forked) { MCML_HIP(hipStreamWaitEvent(sM, c.ev_leaf, 0)); forked = false; }   // leaf(t) done
+        if (nb2 > 0) {
+            // the next diagonal block: its multiplier, its update, its factorisation
+            MCML_TRY(gemm_nt(nb2, nb, nb, A21, Linv, CHOL_NB, A21, 1.0, 0.0, false, 7, 1, 0));
+            double* T = A11 + nb + (size_t)nb * lda;
+            MCML_TRY(gemm_nt(nb2, nb2, nb, A21, A21, lda, T, -1.0, 1.0, false, 8, 0, 0));
+            if (two) {
+                MCML_HIP(hipEventRecord(c.ev_col, sM));
+                MCML_HIP(hipStreamWaitEvent(sL, c.ev_col, 0));
+            }
+            MCML_TRY(leaf(sL, k + nb, nb2));
+            if (two) { MCML_HIP(hipEventRecord(c.ev_leaf, sL)); forked = true; }
         }
-        double* A22 = A11 + nb + (size_t)nb * lda;
-        const int nb2 = rem < CHOL_NB ? rem : CHOL_NB;
-        const bool la = la_any && rem - nb2 >= la_min;
-        if (!la) {
-            EpiAxpby epi{A22, lda, -1.0, 1.0};
-            MCML_TRY(chol_gemm<true>(c.stream, rem, rem, nb, A21, lda, A21, lda, epi, true, 0));
-            MCML_TRY(leaf(c.stream, k + nb, nb2));
-            continue;
+        // the bulk: the rest of the panel, then the whole trailing update except the block above
+        if (R - nb2 > 0)
+            MCML_TRY(gemm_nt(R - nb2, nb, nb, A21 + nb2, Linv, CHOL_NB, A21 + nb2, 1.0, 0.0, false, 0, 1, 0));
+        if (rem > 0 && R - nb2 > 0) {
+            double* C2 = A11 + nb + nb2 + (size_t)nb * lda;       // rows nb2.. of the trailing matrix, all its columns
+            MCML_TRY(gemm_nt(R - nb2, rem, nb, A21 + nb2, A21, lda, C2, -1.0, 1.0, true, 0, 0, nb2));
         }
-        {   // the next panel's columns (its upper triangle inside the diagonal block is scratch)
-            EpiAxpby epi{A22, lda, -1.0, 1.0};
-            MCML_TRY(chol_gemm<true>(c.stream, rem, nb2, nb, A21, lda, A21, lda, epi, false, 0));
-        }
-        MCML_HIP(hipEventRecord(c.ev_col, c.stream));
-        MCML_HIP(hipStreamWaitEvent(c.aux, c.ev_col, 0));
-        MCML_TRY(leaf(c.aux, k + nb, nb2));
-        MCML_HIP(hipEventRecord(c.ev_leaf, c.aux));
-        const int rem2 = rem - nb2;
-        if (rem2 > 0) {
-            EpiAxpby epi{A22 + nb2 + (size_t)nb2 * lda, lda, -1.0, 1.0};
-            MCML_TRY(chol_gemm<true>(c.stream, rem2, rem2, nb, A21 + nb2, lda, A21 + nb2, lda, epi, true, 0));
-        }
-        MCML_HIP(hipStreamWaitEvent(c.stream, c.ev_leaf, 0));
     }
+    if (forked) MCML_HIP(hipStreamWaitEvent(sM, c.ev_leaf, 0));
     return MCML_OK;
 }
 
@@ -705,7 +747,7 @@ int potrf_lower(Ctx& c, double* A, int n, int lda)
     // the leaves write the lower triangles of their inverses only (k_potrf_leaf)
     MCML_HIP(hipMemsetAsync(c.linv.p, 0, sizeof(double) * (size_t)((n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB, c.stream));
     MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_potrf_leaf), (int)POTRF_LDS));
-    if (chol_blocked()) return potrf_blocked(c, A, lda, n);
+    if (chol_blocked()) return potrf_blocked(c, A, lda, n, 0);
     return potrf_rec(c, A, lda, 0, n);
 }
 
@@ -852,24 +894,51 @@ int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out)
         MCML_HIP(hipStreamSynchronize(c.stream));   // ids is a host temporary
     }
     if (c.maxdim_large > 0) {
-        MCML_TRY(c.Uwork.alloc(c.maxdim_large, m));
+        // blocked path: the m sample columns ride below the matrix as m extra rows (U', one sample per row), so
+        // the forward substitution happens inside the factorisation (potrf_blocked); recursive path: separate TRSM
+        const bool aug = chol_blocked();
+        if (aug) {
+            if (c.Dwork.rows < c.maxdim_large + 2 + m || c.Dwork.cols < c.maxdim_large + 2) {
+                MCML_TRY(c.Dwork.alloc(c.maxdim_large + 2 + m, c.maxdim_large + 2));
+                MCML_HIP(hipMemsetAsync(c.Dwork.d(), 0, sizeof(double) * (size_t)c.Dwork.ld * (c.maxdim_large + 2), c.stream));
+            }
+        } else {
+            MCML_TRY(c.Uwork.alloc(c.maxdim_large, m));
+        }
         for (int b = 0; b < cs.B; ++b) {
             const CovBlock& blk = cs.blocks[b];
             if (blk.all_gr || blk.dim <= SMALL_BLOCK) continue;
             const int d = blk.dim;
             dim3 g((d + 15) / 16, (d + 15) / 16);
+            const int dp = aug ? round_up(d, 2) : d;      // even: the extra rows and every panel stay 16-byte aligned
+            g = dim3((dp + 15) / 16, (dp + 15) / 16);
             hipLaunchKernelGGL(k_build_dense, g, dim3(256), 0, c.stream, c.Dwork.d(), c.Dwork.ld, b, dblk, dcov,
-                               cs.rows, c.d_data.d(), th, 0);
+                               cs.rows, c.d_data.d(), th, 0, dp);
             MCML_HIP(hipGetLastError());
-            MCML_TRY(potrf_lower(c, c.Dwork.d(), d, c.Dwork.ld));
-            int gy = m < 256 ? m : 256;
-            hipLaunchKernelGGL(k_copy_block, dim3((d + 255) / 256, gy), dim3(256), 0, c.stream, c.Uwork.d(),
-                               c.Uwork.ld, c.U.d() + blk.matstart, c.U.ld, d, m);
-            MCML_HIP(hipGetLastError());
-            MCML_TRY(trsm_left_lower(c, c.Dwork.d(), c.Dwork.ld, d, c.Uwork.d(), c.Uwork.ld, m));
-            int gx = (d + 255) / 256; gy = m < 64 ? m : 64;
+            const double* Z; int ldz, zr, zc;        // the solved samples: zr x zc, sum of squares wanted
+            if (aug) {
+                hipLaunchKernelGGL(k_transpose_in, dim3((d + 31) / 32, (m + 31) / 32), dim3(256), 0, c.stream,
+                                   c.U.d() + blk.matstart, c.U.ld, d, m, c.Dwork.d() + dp, c.Dwork.ld);
+                if (dp > d)        // the border column of the sample rows must be finite: it meets zeros only
+                    MCML_HIP(hipMemsetAsync(c.Dwork.d() + dp + (size_t)d * c.Dwork.ld, 0, sizeof(double) * m, c.stream));
+                MCML_HIP(hipGetLastError());
+                MCML_TRY(c.linv.ensure(sizeof(double) * (size_t)(dp / CHOL_NB + 1) * CHOL_NB * CHOL_NB));
+                MCML_HIP(hipMemsetAsync(c.linv.p, 0, sizeof(double) * (size_t)((dp + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB, c.stream));
+                MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_potrf_leaf), (int)POTRF_LDS));
+                MCML_TRY(potrf_blocked(c, c.Dwork.d(), c.Dwork.ld, dp, m));
+                Z = c.Dwork.d() + dp; ldz = c.Dwork.ld; zr = m; zc = d;
+            } else {
+                MCML_TRY(potrf_lower(c, c.Dwork.d(), d, c.Dwork.ld));
+                int gy = m < 256 ? m : 256;
+                hipLaunchKernelGGL(k_copy_block, dim3((d + 255) / 256, gy), dim3(256), 0, c.stream, c.Uwork.d(),
+                                   c.Uwork.ld, c.U.d() + blk.matstart, c.U.ld, d, m);
+                MCML_HIP(hipGetLastError());
+                MCML_TRY(trsm_left_lower(c, c.Dwork.d(), c.Dwork.ld, d, c.Uwork.d(), c.Uwork.ld, m));
+                Z = c.Uwork.d(); ldz = c.Uwork.ld; zr = d; zc = m;
+            }
+            int gx = (zr + 255) / 256, gy = zc < 64 ? zc : 64;
             MCML_TRY(c.partials.ensure(sizeof(double) * (size_t)(gx * gy + 16)));
-            hipLaunchKernelGGL(k_sumsq, dim3(gx, gy), dim3(256), 0, c.stream, c.Uwork.d(), c.Uwork.ld, d, m, c.partials.d());
+            hipLaunchKernelGGL(k_sumsq, dim3(gx, gy), dim3(256), 0, c.stream, Z, ldz, zr, zc, c.partials.d());
             hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, c.partials.d(), gx * gy, 1.0, scal + 2, 0);
             hipLaunchKernelGGL(k_logdet, dim3(1), dim3(256), 0, c.stream, c.Dwork.d(), c.Dwork.ld, d, scal + 1);
             hipLaunchKernelGGL(k_finish_large, dim3(1), dim3(1), 0, c.stream, scal, d, m);
@@ -915,7 +984,7 @@ int mvn_gen_L(Ctx& c, const double* theta, bool chol)
         double* A = c.L.at(blk.matstart, blk.matstart);
         dim3 g((d + 15) / 16, (d + 15) / 16);
         hipLaunchKernelGGL(k_build_dense, g, dim3(256), 0, c.stream, A, c.L.ld, b, dblk, dcov, cs.rows,
-                           c.d_data.d(), th, chol ? 0 : 1);
+                           c.d_data.d(), th, chol ? 0 : 1, d);
         MCML_HIP(hipGetLastError());
         if (chol) {
             // blocks start at arbitrary (possibly odd) offsets: factorise in the

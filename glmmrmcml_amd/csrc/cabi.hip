@@ -233,6 +233,9 @@ extern "C" int glmmr_mcml_ctx_set_L(glmmr_mcml_ctx* h, const double* L, int ldl)
     MCML_HIP(hipSetDevice(c.device));
     MCML_TRY(upload_matrix(c.L, L, c.Q, c.Q, ldl, c.stream));
     c.have_L = true;
+    // a caller-supplied L need not have the block pattern the sparse ZL operator assumes (entries outside the
+    // covariance blocks would be dropped): the dense products take whatever L holds
+    c.no_sparse_zl = true;
     MCML_TRY(model_update_L(c));
     return c.sync();
 }

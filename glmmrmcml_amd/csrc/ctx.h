@@ -34,7 +34,12 @@ struct SparseZL {
     int W = 0;                       // ELL width
     long nnz = 0;
     DevBuf ell_col, ell_src, ell_z, ell_val;   // n x W (column-major): column of ZL, flat index into L, Z value, value
-    DevBuf csr_ptr, csr_i, csr_pos;            // rows of ZL' : q -> (observation, position in ell_val)
+    DevBuf csr_ptr, csr_i, csr_pos, csr_val;   // rows of ZL' : q -> (observation, position in ell_val, value)
+    DevBuf row_start;                          // first column of row q of the block-diagonal L (U = L V, hmc.hip)
+    // per covariance block (all of dimension <= 16): the observations that touch it and, per observation, where in
+    // ell_val the block's effects sit (k_sp_backward_block); nblk = 0 when the structure does not apply
+    int nblk = 0, blk_dmax = 0;
+    DevBuf blk_ptr, blk_start, blk_dim, blk_obs, blk_idx;
 };
 
 // HIP-event timing of the dominant kernels, on the stream they are launched on

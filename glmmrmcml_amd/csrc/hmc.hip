@@ -62,6 +62,19 @@ struct EpiForwardT {
         if (store_mu) MU[m + (size_t)n * ld] = mu;
         S[m + (size_t)n * ld] = score(y[m], mu);
     }
+    // two consecutive rows (m even) of one column with 16-byte accesses; the per-row data is loaded once per
+    // thread (row2) and reused for every chain
+    struct Row2 { d2 xb2, y2; };
+    __device__ __forceinline__ Row2 row2(int m) const {
+        return Row2{*reinterpret_cast<const d2*>(xb + m), *reinterpret_cast<const d2*>(y + m)};
+    }
+    __device__ __forceinline__ void elem2(const Row2& r, int m, int n, double a0, double a1) const {
+        d2 mu; mu.x = r.xb2.x + a0; mu.y = r.xb2.y + a1;
+        const size_t off = m + (size_t)n * ld;
+        if (store_mu) *reinterpret_cast<d2*>(MU + off) = mu;
+        d2 sc; sc.x = score(r.y2.x, mu.x); sc.y = score(r.y2.y, mu.y);
+        *reinterpret_cast<d2*>(S + off) = sc;
+    }
     // Three phases -- all loads, all arithmetic, all stores -- with no use of a loaded register after the first
     // store.  The compiler's waitcnt insertion cannot count stores issued under divergent control flow, so any
     // such use gets `s_waitcnt vmcnt(0)`, and vector memory completes in order: that wait also drains every store
@@ -127,6 +140,27 @@ struct EpiBackward {
                 UP[off] = x + en * rr;
             }
             R[off] = rr;
+        }
+    }
+    struct Row2 {};
+    __device__ __forceinline__ Row2 row2(int) const { return Row2{}; }
+    __device__ __forceinline__ void elem2(const Row2&, int m, int n, double a0, double a1) const {
+        int st = 0; double en = 0.0;
+        if (mode == 1) { st = steps[n]; en = e[n]; if (s >= st) return; }
+        const size_t off = m + (size_t)n * ld;
+        const d2 x = *reinterpret_cast<const d2*>(Xs + off);
+        d2 g; g.x = -1.0 * x.x; g.y = -1.0 * x.y;
+        g.x = g.x + post * a0; g.y = g.y + post * a1;
+        if (mode != 1 || s + 1 >= st) *reinterpret_cast<d2*>(G + off) = g;
+        if (mode == 1) {
+            d2 rr = *reinterpret_cast<const d2*>(R + off);
+            rr.x = rr.x + (en / 2) * g.x; rr.y = rr.y + (en / 2) * g.y;
+            if (s + 1 < st) {
+                rr.x = rr.x + (en / 2) * g.x; rr.y = rr.y + (en / 2) * g.y;
+                d2 up; up.x = x.x + en * rr.x; up.y = x.y + en * rr.y;
+                *reinterpret_cast<d2*>(UP + off) = up;
+            }
+            *reinterpret_cast<d2*>(R + off) = rr;
         }
     }
     // Per 16-column group: all loads (from clamped, always valid addresses), then all arithmetic into
@@ -200,51 +234,222 @@ struct EpiBackward {
 };
 
 // ------------------------------------------------------------------ sparse ZL products
-// forward: acc = sum_k ZL[i, col_k] X[col_k, c]   (ELL row of observation i)
+// HBM-bound gathers (configs 1, 4, 5).  The state matrices are column-major with the chain as column, so the
+// coalesced dimension is the observation / random effect: a thread owns one row of the operator, keeps that
+// row's (column, value) pairs in registers (they do not depend on the chain) and walks the chains CHUNK at a
+// time with all gathers of a chunk issued before the first use.  Neighbouring threads read neighbouring or equal
+// addresses (the observations of a cluster-period share their columns; the per-observation effect of config 5 is
+// contiguous), and every store is a full coalesced line.
+constexpr int SP_MAXW = 8;        // ELL widths up to this keep the row in registers
+constexpr int SP_CHUNK = 4;       // chains per batch of gathers
+
+// forward: acc = sum_k ZL[i, col_k] X[col_k, c]   (ELL row of observation i).
+// One workgroup = ONE chain x SP_RPT x 256 consecutive observations: every stream it touches (the state
+// column, S, MU) is one long contiguous run (16 KB), which is what the HBM controllers want -- 256-row x
+// many-chain tiles touch 2 KB runs 160 KB apart and ran at half the rate.  The ELL (column, value) pairs are
+// re-read per chain, from L2 (they are a few hundred KB).  SP_RPT independent rows per thread keep the gathers
+// in flight.
+constexpr int SP_RPT = 8;
+// A thread owns SP_RPT/2 PAIRS of adjacent observations: the ELL pairs and everything the epilogue touches move 16
+// bytes per lane (the state gathers stay scalar).
 template <class Epi>
 __global__ __launch_bounds__(256) void k_sp_forward(int n, int C, int W, const int* col, const double* val,
-                                                    const double* X, int ldx, Epi epi)
+                                                    const double* X, int ldx, int cpb, Epi epi)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    for (int c = blockIdx.y; c < C; c += gridDim.y) {
-        const double* x = X + (size_t)c * ldx;
-        double acc = 0.0;
-        for (int k = 0; k < W; ++k) acc += val[i + (size_t)k * n] * x[col[i + (size_t)k * n]];
-        epi.elem(i, c, acc);
+    (void)cpb; (void)C;
+    const int c = blockIdx.y;
+    const int base = blockIdx.x * (256 * SP_RPT) + 2 * threadIdx.x;
+    const double* x = X + (size_t)c * ldx;
+    const bool vec = (n & 1) == 0;                         // column k of the ELL arrays starts 8- / 16-byte aligned
+    double a0[SP_RPT / 2], a1[SP_RPT / 2];
+#pragma unroll
+    for (int j = 0; j < SP_RPT / 2; ++j) {
+        const int i = base + 512 * j;
+        double s0 = 0.0, s1 = 0.0;
+        if (i + 1 < n && vec) {
+            for (int k = 0; k < W; ++k) {
+                const int2 cc = *reinterpret_cast<const int2*>(col + i + (size_t)k * n);
+                const d2 vv = *reinterpret_cast<const d2*>(val + i + (size_t)k * n);
+                s0 += vv.x * x[cc.x]; s1 += vv.y * x[cc.y];
+            }
+        } else if (i < n) {
+            for (int k = 0; k < W; ++k) {
+                s0 += val[i + (size_t)k * n] * x[col[i + (size_t)k * n]];
+                if (i + 1 < n) s1 += val[i + 1 + (size_t)k * n] * x[col[i + 1 + (size_t)k * n]];
+            }
+        }
+        a0[j] = s0; a1[j] = s1;
+    }
+#pragma unroll
+    for (int j = 0; j < SP_RPT / 2; ++j) {
+        const int i = base + 512 * j;
+        if (i + 1 < n) epi.elem2(epi.row2(i), i, c, a0[j], a1[j]);
+        else if (i < n) epi.elem(i, c, a0[j]);
     }
 }
 
-// backward: acc = sum_t ZL[i_t, q] S[i_t, c]   (CSR row q of ZL')
+// backward, short rows: acc = sum_t ZL[i_t, q] S[i_t, c]   (CSR row q of ZL'); same geometry: one chain, SP_RPT x 256
+// consecutive random effects per workgroup; `val` is the CSR-ordered copy of the values (no position
+// indirection).  (Pairs of adjacent effects per thread with 16-byte epilogue accesses, which pay in the forward
+// product, measured 25 % SLOWER here: 496 vs 401 us at config 5.)
 template <class Epi>
 __global__ __launch_bounds__(256) void k_sp_backward(int Q, int C, const int* ptr, const int* ci, const int* cp,
-                                                     const double* val, const double* S, int lds, Epi epi)
+                                                     const double* val, const double* S, int lds, int cpb, Epi epi)
+{
+    (void)cpb; (void)C; (void)cp;
+    const int c = blockIdx.y;
+    const int base = blockIdx.x * (256 * SP_RPT) + threadIdx.x;
+    const double* sc = S + (size_t)c * lds;
+    double acc[SP_RPT];
+#pragma unroll
+    for (int j = 0; j < SP_RPT; ++j) {
+        const int q = base + 256 * j;
+        double a = 0.0;
+        if (q < Q) {
+            const int t0 = ptr[q], t1 = ptr[q + 1];
+            for (int t = t0; t < t1; ++t) a += val[t] * sc[ci[t]];
+        }
+        acc[j] = a;
+    }
+#pragma unroll
+    for (int j = 0; j < SP_RPT; ++j) {
+        const int q = base + 256 * j;
+        if (q < Q) epi.elem(q, c, acc[j]);
+    }
+}
+
+// backward when the rows are long AND the covariance blocks are small (config 4: 40 blocks of 8 effects, 400
+// observations each): the rows of one block share their observations, so reading S once per ROW reads it
+// dim times.  One wave per (block, 4 chains): the lanes stride the block's observation list (consecutive
+// observations: coalesced), each observation's values for the block's effects sit in registers for all the
+// chains (idx[t][j] = position in ell_val of ZL[obs_t, start + j], or -1), every S element is read ONCE and
+// multiplied into DMAX accumulators; butterfly wave reduction (fixed order), then lane 8u + j finishes
+// (effect j, chain u).
+constexpr int SPB_KEEP = 8;
+template <int DMAX, class Epi>
+__global__ __launch_bounds__(256) void k_sp_backward_block(int nblk, int C, const int* bptr, const int* bstart,
+                                                           const int* bdim, const int* bobs, const int* bidx,
+                                                           const double* val, const double* S, int lds, int cpb, Epi epi)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const int p0 = bptr[b], p1 = bptr[b + 1], bs = bstart[b], d = bdim[b];
+    const int c0 = blockIdx.y * cpb, c1 = (c0 + cpb < C) ? c0 + cpb : C;
+    int il[SPB_KEEP]; double vl[SPB_KEEP][DMAX];
+#pragma unroll
+    for (int k = 0; k < SPB_KEEP; ++k) {
+        const int t = p0 + lane + 64 * k;
+        const bool in = t < p1;
+        il[k] = in ? bobs[t] : 0;
+#pragma unroll
+        for (int j = 0; j < DMAX; ++j) {
+            const int ix = in ? bidx[(size_t)t * DMAX + j] : -1;
+            vl[k][j] = ix >= 0 ? val[ix] : 0.0;
+        }
+    }
+    const int tk = p0 + 64 * SPB_KEEP;
+    for (int c = c0 + SP_CHUNK * w; c < c1; c += SP_CHUNK * 4) {
+        double acc[SP_CHUNK][DMAX];
+#pragma unroll
+        for (int u = 0; u < SP_CHUNK; ++u)
+#pragma unroll
+            for (int j = 0; j < DMAX; ++j) acc[u][j] = 0.0;
+#pragma unroll
+        for (int k = 0; k < SPB_KEEP; ++k) {
+            double sv[SP_CHUNK];
+#pragma unroll
+            for (int u = 0; u < SP_CHUNK; ++u) sv[u] = S[il[k] + (size_t)((c + u < c1) ? c + u : c1 - 1) * lds];
+#pragma unroll
+            for (int u = 0; u < SP_CHUNK; ++u)
+#pragma unroll
+                for (int j = 0; j < DMAX; ++j) acc[u][j] += vl[k][j] * sv[u];
+        }
+        for (int t = tk + lane; t < p1; t += 64) {           // observation lists longer than 64 x SPB_KEEP
+            const int it = bobs[t];
+#pragma unroll
+            for (int j = 0; j < DMAX; ++j) {
+                const int ix = bidx[(size_t)t * DMAX + j];
+                const double v = ix >= 0 ? val[ix] : 0.0;
+#pragma unroll
+                for (int u = 0; u < SP_CHUNK; ++u) acc[u][j] += v * S[it + (size_t)((c + u < c1) ? c + u : c1 - 1) * lds];
+            }
+        }
+        // all-lanes sums (xor butterfly: the same tree in every lane), then lane DMAX u + j takes (j, u)
+        double mine = 0.0;
+#pragma unroll
+        for (int u = 0; u < SP_CHUNK; ++u)
+#pragma unroll
+            for (int j = 0; j < DMAX; ++j) {
+                double v = acc[u][j];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                if (lane == u * DMAX + j) mine = v;
+            }
+        if (lane < SP_CHUNK * DMAX) {
+            const int u = lane / DMAX, j = lane - u * DMAX;
+            if (j < d && c + u < c1) epi.elem(bs + j, c + u, mine);
+        }
+    }
+}
+
+// backward for long rows (tens to hundreds of observations per random effect, config 4): one wave per random
+// effect; the lanes stride the row (its observations are mostly consecutive: coalesced) and keep up to SPW_KEEP
+// (observation, value) pairs each in registers for all the chains; SP_CHUNK chains are reduced together so that
+// the shuffles of one chain overlap the loads of the next.  Fixed-order wave reduction.
+constexpr int SPW_KEEP = 8;       // 64 x 8 = 512 entries per row in registers; longer rows re-read the tail
+template <class Epi>
+__global__ __launch_bounds__(256) void k_sp_backward_wave(int Q, int C, const int* ptr, const int* ci, const int* cp,
+                                                          const double* val, const double* S, int lds, int cpb, Epi epi)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + w;
+    if (q >= Q) return;
+    const int t0 = ptr[q], t1 = ptr[q + 1];
+    const int c0 = blockIdx.y * cpb, c1 = (c0 + cpb < C) ? c0 + cpb : C;
+    int il[SPW_KEEP]; double vl[SPW_KEEP];
+#pragma unroll
+    for (int k = 0; k < SPW_KEEP; ++k) {
+        const int t = t0 + lane + 64 * k;
+        const bool in = t < t1;
+        il[k] = in ? ci[t] : 0;
+        vl[k] = in ? val[cp[t]] : 0.0;
+    }
+    const int tk = t0 + 64 * SPW_KEEP;                     // first entry not held in registers
+    for (int c = c0; c < c1; c += SP_CHUNK) {
+        double acc[SP_CHUNK];
+#pragma unroll
+        for (int u = 0; u < SP_CHUNK; ++u) {
+            const int cc = (c + u < c1) ? c + u : c1 - 1;
+            const double* sc = S + (size_t)cc * lds;
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < SPW_KEEP; ++k) a += vl[k] * sc[il[k]];
+            for (int t = tk + lane; t < t1; t += 64) a += val[cp[t]] * sc[ci[t]];
+            acc[u] = a;
+        }
+#pragma unroll
+        for (int u = 0; u < SP_CHUNK; ++u) acc[u] = wave_sum(acc[u]);
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < SP_CHUNK; ++u)
+                if (c + u < c1) epi.elem(q, c + u, acc[u]);
+        }
+    }
+}
+
+// U = L V for a block-diagonal L with small blocks (the sparse-ZL configurations): row q of L has entries in
+// columns start(q) .. q only.  Dense, this product is Q x Q x m (22 ms at config 5 for what is a diagonal scaling).
+__global__ __launch_bounds__(256) void k_blockdiag_LV(int Q, int ncols, const int* start, const double* L, int ldl,
+                                                      const double* V, int ldv, double* U, int ldu)
 {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= Q) return;
-    const int t0 = ptr[q], t1 = ptr[q + 1];
-    for (int c = blockIdx.y; c < C; c += gridDim.y) {
-        const double* sc = S + (size_t)c * lds;
+    const int s0 = start[q];
+    for (int c = blockIdx.y; c < ncols; c += gridDim.y) {
+        const double* v = V + (size_t)c * ldv;
         double acc = 0.0;
-        for (int t = t0; t < t1; ++t) acc += val[cp[t]] * sc[ci[t]];
-        epi.elem(q, c, acc);
-    }
-}
-
-// backward for long rows (tens to hundreds of observations per random effect): one wave per
-// (q, chain), lanes stride the row, fixed-order wave reduction
-template <class Epi>
-__global__ __launch_bounds__(256) void k_sp_backward_wave(int Q, int C, const int* ptr, const int* ci, const int* cp,
-                                                          const double* val, const double* S, int lds, Epi epi)
-{
-    const int q = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int t0 = ptr[q], t1 = ptr[q + 1];
-    for (int c = blockIdx.y * 4 + w; c < C; c += gridDim.y * 4) {
-        const double* sc = S + (size_t)c * lds;
-        double acc = 0.0;
-        for (int t = t0 + lane; t < t1; t += 64) acc += val[cp[t]] * sc[ci[t]];
-        acc = wave_sum(acc);
-        if (lane == 0) epi.elem(q, c, acc);
+        for (int t = s0; t <= q; ++t) acc += L[q + (size_t)t * ldl] * v[t];
+        U[q + (size_t)c * ldu] = acc;
     }
 }
 
@@ -458,15 +663,29 @@ static bool use_dlds()
     return v == 1;
 }
 
+// chains per workgroup (a multiple of SP_CHUNK) and grid.y for the sparse products: enough workgroups to fill the
+// chip several times over (>= ~4096 of 256 threads), as few chain splits as that allows (a row's indices and
+// values are loaded once per split)
+static void sp_chain_split(int rows, int C, int& cpb, int& gy)
+{
+    const int gx = (rows + 255) / 256;
+    int want = (4096 + gx - 1) / gx;                      // splits wanted
+    if (want < 1) want = 1;
+    cpb = (C + want - 1) / want;
+    cpb = (cpb + SP_CHUNK - 1) / SP_CHUNK * SP_CHUNK;
+    if (cpb < SP_CHUNK) cpb = SP_CHUNK;
+    gy = (C + cpb - 1) / cpb;
+}
+
 // MU = xb + ZL * X ; S = score
 template <class Epi>
 static int hmc_forward_launch(Ctx& c, const double* X, int ldx, const Epi& epi)
 {
     HmcState& h = c.hmc;
     if (c.sp.active) {
-        const int gy = h.C < 256 ? h.C : 256;
-        hipLaunchKernelGGL((k_sp_forward<Epi>), dim3((c.n + 255) / 256, gy), dim3(256), 0, c.stream, c.n, h.C,
-                           c.sp.W, c.sp.ell_col.as<int>(), c.sp.ell_val.d(), X, ldx, epi);
+        const int cpb = 1, gy = h.C;
+        hipLaunchKernelGGL((k_sp_forward<Epi>), dim3((c.n + 256 * SP_RPT - 1) / (256 * SP_RPT), gy), dim3(256), 0, c.stream, c.n, h.C,
+                           c.sp.W, c.sp.ell_col.as<int>(), c.sp.ell_val.d(), X, ldx, cpb, epi);
         return (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
     }
     if (c.band_fwd && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
@@ -498,17 +717,34 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
     EpiBackward epi{Xs, G, h.R.d(), h.UP.d(), h.V.ld, ca.e, ca.steps, s, glm_score_post(var_par, c.flink), mode};
     const int slot = c.prof.begin(c.stream, 1, chain);
     int rc;
-    if (c.sp.active && c.sp.nnz >= 24L * c.Q) {
-        int gy = (h.C + 3) / 4; if (gy > 64) gy = 64;
-        hipLaunchKernelGGL((k_sp_backward_wave<EpiBackward>), dim3(c.Q, gy), dim3(256), 0, c.stream, c.Q, h.C,
+    static const bool use_block = getenv("GLMMR_MCML_SPB") != nullptr && atoi(getenv("GLMMR_MCML_SPB")) != 0;   // measured 90 vs 78 us (wave kernel) at config 4: off
+    if (c.sp.active && c.sp.nnz >= 24L * c.Q && c.sp.nblk > 0 && use_block) {
+        // long rows in small covariance blocks: a wave per (block, 4 chains), S read once
+        int cpb = (h.C * c.sp.nblk + 4095) / 4096;                 // ~4096 waves in all
+        cpb = (cpb + 4 * SP_CHUNK - 1) / (4 * SP_CHUNK) * (4 * SP_CHUNK);
+        const int gy = (h.C + cpb - 1) / cpb;
+        if (c.sp.blk_dmax <= 8)
+            hipLaunchKernelGGL((k_sp_backward_block<8, EpiBackward>), dim3(c.sp.nblk, gy), dim3(256), 0, c.stream, c.sp.nblk, h.C,
+                               c.sp.blk_ptr.as<int>(), c.sp.blk_start.as<int>(), c.sp.blk_dim.as<int>(), c.sp.blk_obs.as<int>(),
+                               c.sp.blk_idx.as<int>(), c.sp.ell_val.d(), h.S.d(), h.S.ld, cpb, epi);
+        else
+            hipLaunchKernelGGL((k_sp_backward_block<16, EpiBackward>), dim3(c.sp.nblk, gy), dim3(256), 0, c.stream, c.sp.nblk, h.C,
+                               c.sp.blk_ptr.as<int>(), c.sp.blk_start.as<int>(), c.sp.blk_dim.as<int>(), c.sp.blk_obs.as<int>(),
+                               c.sp.blk_idx.as<int>(), c.sp.ell_val.d(), h.S.d(), h.S.ld, cpb, epi);
+        rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
+    } else if (c.sp.active && c.sp.nnz >= 24L * c.Q) {
+        // long rows: a wave per random effect, 4 per workgroup; chains split so that the grid has >= ~2000 workgroups
+        int cpb, gy;
+        sp_chain_split(64 * ((c.Q + 3) / 4) * 4, h.C, cpb, gy);
+        hipLaunchKernelGGL((k_sp_backward_wave<EpiBackward>), dim3((c.Q + 3) / 4, gy), dim3(256), 0, c.stream, c.Q, h.C,
                            c.sp.csr_ptr.as<int>(), c.sp.csr_i.as<int>(), c.sp.csr_pos.as<int>(), c.sp.ell_val.d(),
-                           h.S.d(), h.S.ld, epi);
+                           h.S.d(), h.S.ld, cpb, epi);
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
     } else if (c.sp.active) {
-        const int gy = h.C < 256 ? h.C : 256;
-        hipLaunchKernelGGL((k_sp_backward<EpiBackward>), dim3((c.Q + 255) / 256, gy), dim3(256), 0, c.stream, c.Q, h.C,
-                           c.sp.csr_ptr.as<int>(), c.sp.csr_i.as<int>(), c.sp.csr_pos.as<int>(), c.sp.ell_val.d(),
-                           h.S.d(), h.S.ld, epi);
+        const int cpb = 1, gy = h.C;
+        hipLaunchKernelGGL((k_sp_backward<EpiBackward>), dim3((c.Q + 256 * SP_RPT - 1) / (256 * SP_RPT), gy), dim3(256), 0, c.stream, c.Q, h.C,
+                           c.sp.csr_ptr.as<int>(), c.sp.csr_i.as<int>(), c.sp.csr_pos.as<int>(), c.sp.csr_val.d(),
+                           h.S.d(), h.S.ld, cpb, epi);
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
     } else if (c.band_bwd && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
         rc = launch_gemm_band(c.stream, c.plan_bwd, h.C, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
@@ -641,7 +877,12 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
     // return (L * samples)  (mhmcmc.h:155)
     MCML_TRY(c.U.alloc(Q, ncols));
     MCML_HIP(hipMemsetAsync(c.U.d(), 0, sizeof(double) * (size_t)c.U.ld * ncols, c.stream));
-    {
+    if (c.sp.active && c.sp.row_start.p) {
+        int gy = ncols < 1024 ? ncols : 1024;
+        hipLaunchKernelGGL(k_blockdiag_LV, dim3((Q + 255) / 256, gy), dim3(256), 0, c.stream, Q, ncols,
+                           c.sp.row_start.as<int>(), c.L.d(), c.L.ld, samp.d(), samp.ld, c.U.d(), c.U.ld);
+        MCML_HIP(hipGetLastError());
+    } else {
         EpiAxpby epi{c.U.d(), c.U.ld, 1.0, 0.0};
         MCML_TRY(launch_gemm<false>(c.stream, Q, ncols, Q, c.L.d(), c.L.ld, samp.d(), samp.ld, epi));
     }

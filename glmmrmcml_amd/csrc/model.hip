@@ -144,6 +144,14 @@ __global__ void k_ell_fill(const int* src, const double* z, const double* L, lon
     if (e < total) val[e] = z[e] * L[src[e]];
 }
 
+// the same values in the order of the rows of ZL' (CSR): the backward product reads them without the
+// position indirection
+__global__ void k_csr_fill(const int* pos, const double* ell_val, long nnz, double* csr_val)
+{
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nnz) csr_val[t] = ell_val[pos[t]];
+}
+
 static int sparse_zl_setup(Ctx& c)
 {
     SparseZL& sp = c.sp;
@@ -192,6 +200,55 @@ static int sparse_zl_setup(Ctx& c)
     MCML_HIP(hipMemcpyAsync(sp.csr_ptr.p, ptr.data(), sizeof(int) * (size_t)(Q + 1), hipMemcpyHostToDevice, c.stream));
     MCML_HIP(hipMemcpyAsync(sp.csr_i.p, ci.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c.stream));
     MCML_HIP(hipMemcpyAsync(sp.csr_pos.p, cp.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c.stream));
+    // ---- block view for the long-row backward product: every covariance block of dimension <= 16
+    sp.nblk = 0; sp.blk_dmax = 0;
+    {
+        int dmax = 0;
+        for (int b = 0; b < c.cov.B; ++b) dmax = std::max(dmax, c.cov.blocks[b].dim);
+        if (dmax >= 2 && dmax <= 16) {
+            const int DM = dmax <= 8 ? 8 : 16, B = c.cov.B;
+            std::vector<std::vector<int>> obs(B);
+            std::vector<int> last(B, -1);
+            for (int i = 0; i < n; ++i)
+                for (int w = 0; w < width[i]; ++w) {
+                    const int b = blk_of[col[i + (size_t)w * n]];
+                    if (last[b] != i) { obs[b].push_back(i); last[b] = i; }
+                }
+            std::vector<int> bptr(B + 1, 0), bstart(B), bdim(B), bobs, bidx;
+            bool ok = true;
+            for (int b = 0; b < B && ok; ++b) {
+                bstart[b] = c.cov.blocks[b].matstart; bdim[b] = c.cov.blocks[b].dim;
+                for (int i : obs[b]) {
+                    const size_t base = bidx.size();
+                    bidx.resize(base + DM, -1);
+                    for (int w = 0; w < width[i]; ++w) {
+                        const int q = col[i + (size_t)w * n];
+                        if (blk_of[q] != b) continue;
+                        int& slot = bidx[base + (q - bstart[b])];
+                        if (slot >= 0) { ok = false; break; }      // two entries of one observation on one effect: keep the CSR kernels
+                        slot = i + w * n;
+                    }
+                    bobs.push_back(i);
+                    if (!ok) break;
+                }
+                bptr[b + 1] = (int)bobs.size();
+            }
+            if (ok && !bobs.empty()) {
+                MCML_TRY(sp.blk_ptr.ensure(sizeof(int) * bptr.size())); MCML_TRY(sp.blk_start.ensure(sizeof(int) * B));
+                MCML_TRY(sp.blk_dim.ensure(sizeof(int) * B)); MCML_TRY(sp.blk_obs.ensure(sizeof(int) * bobs.size()));
+                MCML_TRY(sp.blk_idx.ensure(sizeof(int) * bidx.size()));
+                MCML_HIP(hipMemcpyAsync(sp.blk_ptr.p, bptr.data(), sizeof(int) * bptr.size(), hipMemcpyHostToDevice, c.stream));
+                MCML_HIP(hipMemcpyAsync(sp.blk_start.p, bstart.data(), sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
+                MCML_HIP(hipMemcpyAsync(sp.blk_dim.p, bdim.data(), sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
+                MCML_HIP(hipMemcpyAsync(sp.blk_obs.p, bobs.data(), sizeof(int) * bobs.size(), hipMemcpyHostToDevice, c.stream));
+                MCML_HIP(hipMemcpyAsync(sp.blk_idx.p, bidx.data(), sizeof(int) * bidx.size(), hipMemcpyHostToDevice, c.stream));
+                MCML_HIP(hipStreamSynchronize(c.stream));
+                sp.nblk = B; sp.blk_dmax = DM;
+            }
+        }
+    }
+    MCML_TRY(sp.row_start.ensure(sizeof(int) * (size_t)Q));
+    MCML_HIP(hipMemcpyAsync(sp.row_start.p, start_of.data(), sizeof(int) * (size_t)Q, hipMemcpyHostToDevice, c.stream));
     MCML_HIP(hipStreamSynchronize(c.stream));
     sp.W = W; sp.nnz = nnz; sp.possible = true;
     return MCML_OK;
@@ -207,6 +264,9 @@ int model_update_L(Ctx& c)
         const long tot = (long)c.n * c.sp.W;
         hipLaunchKernelGGL(k_ell_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c.stream,
                            c.sp.ell_src.as<int>(), c.sp.ell_z.d(), c.L.d(), tot, c.sp.ell_val.d());
+        MCML_TRY(c.sp.csr_val.ensure(sizeof(double) * (size_t)(c.sp.nnz + 1)));
+        hipLaunchKernelGGL(k_csr_fill, dim3((unsigned)((c.sp.nnz + 255) / 256)), dim3(256), 0, c.stream,
+                           c.sp.csr_pos.as<int>(), c.sp.ell_val.d(), c.sp.nnz, c.sp.csr_val.d());
         MCML_HIP(hipGetLastError());
         c.sp.active = true;
         return MCML_OK;
@@ -307,47 +367,64 @@ __global__ __launch_bounds__(256) void k_mcnr_col(const double* ZU, int ldz, int
     if (threadIdx.x == 0) sig[blockIdx.x] = sqrt(r / (n - 1));
 }
 
-// one thread per observation: wsum_j = sum_i W_i,jj ; wusum_j = sum_i W_i,jj * detadmu * resid
-// (mcmlmodel.h:120-134, mcmloptim.h:213-225)
+// wsum_j = sum_i W_i,jj ; wusum_j = sum_i W_i,jj * detadmu * resid   (mcmlmodel.h:120-134, mcmloptim.h:213-225)
+// 2-D grid: (256 observations) x (a chunk of sample columns); each workgroup leaves its chunk's partial sums,
+// k_mcnr_rowsum adds the chunks in order (fixed-order two-stage reduction: n/256 workgroups with a serial loop
+// over all m columns ran at 1 % of the HBM rate)
+constexpr int MCNR_CHUNK = 16;
 __global__ __launch_bounds__(256) void k_mcnr_row(const double* ZU, int ldz, int n, int ncols, const double* xb,
                                                   const double* y, int flink, int link_code, double nvar_par,
-                                                  double* wsum, double* wusum)
+                                                  double* pw, double* pwu, int ldp)
 {
-    int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const double yj = y[j], xbj = xb[j];
+    const int i0 = blockIdx.y * MCNR_CHUNK, i1 = (i0 + MCNR_CHUNK < ncols) ? i0 + MCNR_CHUNK : ncols;
+    double zu[MCNR_CHUNK];
+#pragma unroll
+    for (int u = 0; u < MCNR_CHUNK; ++u) zu[u] = ZU[j + (size_t)((i0 + u < i1) ? i0 + u : i1 - 1) * ldz];
     double a = 0, b = 0;
-    for (int i = 0; i < ncols; ++i) {
-        double eta = xbj + ZU[j + (size_t)i * ldz];
-        double w = 1 / (glm_dhdmu(eta, flink) * nvar_par);
-        double resid = yj - glm_mod_inv(eta, link_code);
-        a += w;
-        b += w * glm_detadmu(eta, link_code) * resid;
-    }
+#pragma unroll
+    for (int u = 0; u < MCNR_CHUNK; ++u)
+        if (i0 + u < i1) {
+            const double eta = xbj + zu[u];
+            const double w = 1 / (glm_dhdmu(eta, flink) * nvar_par);
+            const double resid = yj - glm_mod_inv(eta, link_code);
+            a += w;
+            b += w * glm_detadmu(eta, link_code) * resid;
+        }
+    pw[j + (size_t)blockIdx.y * ldp] = a; pwu[j + (size_t)blockIdx.y * ldp] = b;
+}
+
+__global__ __launch_bounds__(256) void k_mcnr_rowsum(const double* pw, const double* pwu, int ldp, int n, int nchunks,
+                                                     double* wsum, double* wusum)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double a = 0, b = 0;
+    for (int k = 0; k < nchunks; ++k) { a += pw[j + (size_t)k * ldp]; b += pwu[j + (size_t)k * ldp]; }
     wsum[j] = a; wusum[j] = b;
 }
 
 // out[0 .. P*P) = X' diag(wsum) X ; out[P*P .. P*P+P) = X' wusum ; out[P*P+P] = sum sig ;
-// out[P*P+P+1] = number of sample columns summed
+// out[P*P+P+1] = number of sample columns summed.  One workgroup per output.
 __global__ __launch_bounds__(256) void k_mcnr_fin(const double* X, int ldx, int n, int P, const double* wsum,
                                                   const double* wusum, const double* sig, int ncols, double* out)
 {
     __shared__ double sh[4];
-    for (int o = 0; o < P * P + P + 1; ++o) {
-        double acc = 0;
-        if (o < P * P) {
-            int a = o % P, b = o / P;
-            for (int j = threadIdx.x; j < n; j += 256) acc += X[j + (size_t)a * ldx] * wsum[j] * X[j + (size_t)b * ldx];
-        } else if (o < P * P + P) {
-            int a = o - P * P;
-            for (int j = threadIdx.x; j < n; j += 256) acc += X[j + (size_t)a * ldx] * wusum[j];
-        } else {
-            for (int i = threadIdx.x; i < ncols; i += 256) acc += sig[i];
-        }
-        double r = block_sum(acc, sh);
-        if (threadIdx.x == 0) out[o] = r;
+    const int o = blockIdx.x;
+    double acc = 0;
+    if (o < P * P) {
+        const int a = o % P, b = o / P;
+        for (int j = threadIdx.x; j < n; j += 256) acc += X[j + (size_t)a * ldx] * wsum[j] * X[j + (size_t)b * ldx];
+    } else if (o < P * P + P) {
+        const int a = o - P * P;
+        for (int j = threadIdx.x; j < n; j += 256) acc += X[j + (size_t)a * ldx] * wusum[j];
+    } else if (o == P * P + P) {
+        for (int i = threadIdx.x; i < ncols; i += 256) acc += sig[i];
     }
-    if (threadIdx.x == 0) out[P * P + P + 1] = (double)ncols;
+    const double r = block_sum(acc, sh);
+    if (threadIdx.x == 0) out[o] = (o == P * P + P + 1) ? (double)ncols : r;
 }
 
 // stats (host, P*P + P + 2 doubles): sum_i X'W_iX, sum_i X'(W_i detadmu resid_i), sum_i sigma_i
@@ -362,16 +439,20 @@ int model_mcnr_stats(Ctx& c, double var_par, double* stats)
     else if (c.flink >= 9 && c.flink <= 11) nvar_par *= var_par;
     else if (c.flink == 12) nvar_par *= (1 + var_par);
     const int ns = P * P + P + 2;
-    MCML_TRY(c.partials.ensure(sizeof(double) * (size_t)(2 * pad_ld(n) + m + ns + 16)));
+    const int nchunks = (m + MCNR_CHUNK - 1) / MCNR_CHUNK, ldp = pad_ld(n);
+    MCML_TRY(c.partials.ensure(sizeof(double) * ((size_t)(2 + 2 * (size_t)nchunks) * ldp + m + ns + 64)));
     double* wsum = c.partials.d();
-    double* wusum = wsum + pad_ld(n);
-    double* sig = wusum + pad_ld(n);
+    double* wusum = wsum + ldp;
+    double* sig = wusum + ldp;
+    double* pw = sig + round_up(m + 16, 32);
+    double* pwu = pw + (size_t)nchunks * ldp;
     MCML_TRY(c.reduce_buf.ensure(sizeof(double) * (size_t)ns));
     hipLaunchKernelGGL(k_mcnr_col, dim3(m), dim3(256), 0, c.stream, c.ZU.d(), c.ZU.ld, n, c.xb.d(), c.y.d(),
                        c.link_code, sig);
-    hipLaunchKernelGGL(k_mcnr_row, dim3((n + 255) / 256), dim3(256), 0, c.stream, c.ZU.d(), c.ZU.ld, n, m,
-                       c.xb.d(), c.y.d(), c.flink, c.link_code, nvar_par, wsum, wusum);
-    hipLaunchKernelGGL(k_mcnr_fin, dim3(1), dim3(256), 0, c.stream, c.X.d(), c.X.ld, n, P, wsum, wusum, sig, m,
+    hipLaunchKernelGGL(k_mcnr_row, dim3((n + 255) / 256, nchunks), dim3(256), 0, c.stream, c.ZU.d(), c.ZU.ld, n, m,
+                       c.xb.d(), c.y.d(), c.flink, c.link_code, nvar_par, pw, pwu, ldp);
+    hipLaunchKernelGGL(k_mcnr_rowsum, dim3((n + 255) / 256), dim3(256), 0, c.stream, pw, pwu, ldp, n, nchunks, wsum, wusum);
+    hipLaunchKernelGGL(k_mcnr_fin, dim3(ns), dim3(256), 0, c.stream, c.X.d(), c.X.ld, n, P, wsum, wusum, sig, m,
                        c.reduce_buf.d());
     MCML_HIP(hipGetLastError());
     MCML_TRY(allreduce_dev(c, c.reduce_buf.d(), ns));              // RCCL all-reduce of the statistics (comm.hip)

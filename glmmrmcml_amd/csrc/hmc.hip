@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void k_sp_backward_wave(int Q, int C, const in
         const int t = t0 + lane + 64 * k;
         const bool in = t < t1;
         il[k] = in ? ci[t] : 0;
-        vl[k] = in ? val[cp[t]] : 0.0;
+        vl[k] = in ? val[t] : 0.0;          // val = the CSR-ordered copy
     }
     const int tk = t0 + 64 * SPW_KEEP;                     // first entry not held in registers
     for (int c = c0; c < c1; c += SP_CHUNK) {
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void k_sp_backward_wave(int Q, int C, const in
             double a = 0.0;
 #pragma unroll
             for (int k = 0; k < SPW_KEEP; ++k) a += vl[k] * sc[il[k]];
-            for (int t = tk + lane; t < t1; t += 64) a += val[cp[t]] * sc[ci[t]];
+            for (int t = tk + lane; t < t1; t += 64) a += val[t] * sc[ci[t]];
             acc[u] = a;
         }
 #pragma unroll
@@ -737,7 +737,7 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
         int cpb, gy;
         sp_chain_split(64 * ((c.Q + 3) / 4) * 4, h.C, cpb, gy);
         hipLaunchKernelGGL((k_sp_backward_wave<EpiBackward>), dim3((c.Q + 3) / 4, gy), dim3(256), 0, c.stream, c.Q, h.C,
-                           c.sp.csr_ptr.as<int>(), c.sp.csr_i.as<int>(), c.sp.csr_pos.as<int>(), c.sp.ell_val.d(),
+                           c.sp.csr_ptr.as<int>(), c.sp.csr_i.as<int>(), c.sp.csr_pos.as<int>(), c.sp.csr_val.d(),
                            h.S.d(), h.S.ld, cpb, epi);
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
     } else if (c.sp.active) {

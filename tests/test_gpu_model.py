@@ -63,6 +63,10 @@ def test_la_through_the_caller():
     assert np.allclose(f["theta"], g["theta"])
     assert np.all(f["coefficients"]["SE"][:P] > 0) and np.all(g["coefficients"]["SE"][:P + 2] > 0)
     assert f["re_samps"].shape == (d["Q"], 1)
-    # sanity only: the Laplace and the (short, 8-cluster) MCML fits of this model land in the same place
+    # The Laplace and the MCML fits are two estimators of the same beta; nothing says how close a 5-iteration,
+    # 16-chain MCML run of an 8-cluster binomial design must come (round 1 used a bare 0.15, then 0.35, after a
+    # 0.16 gap on the box).  The scale that IS defined is the fit's own standard error: the two estimates differ
+    # by less than two of them, coefficient by coefficient.
     h = m.MCML(d["y"], verbose=False, max_iter=5, seed=3, chains=16, options=dict(maxfun=60))
-    assert np.allclose(f["theta"][:P], h["theta"][:P], atol=0.35)
+    se = np.asarray(f["coefficients"]["SE"][:P])
+    assert np.all(np.abs(np.asarray(f["theta"][:P]) - np.asarray(h["theta"][:P])) < 2.0 * se)

@@ -156,17 +156,23 @@ def main():
     if world > 1:
         collective = "torch.distributed all_reduce hook (%s)" % backend
         if hook is None:
+            # the library's own RCCL communicator (csrc/comm.hip).  Whether it came up is decided TOGETHER: a rank
+            # that failed while the others succeeded would leave the job split over two transports
+            ok = 1
             try:
                 gdist.init_native_rccl(ctx, rank, world)
+            except Exception as e:
+                ok = 0
+                print("bench: rank %d: native RCCL communicator failed (%r)" % (rank, e), file=sys.stderr, flush=True)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
                 collective = "librccl ncclAllReduce on the library's stream (native, no host sync)"
-            except Exception as e:          # a different GPU collective, not a CPU path: say which one ran
-                print("bench: native RCCL communicator failed (%r); using the torch.distributed hook" % (e,),
-                      file=sys.stderr, flush=True)
+            else:       # a different GPU collective, not a CPU path: the line says which one ran
                 ctx.close()
                 hook = gdist.make_reduce_hook()
                 ctx = api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"],
                                   d["link"], device=local_rank, stream=stream, rank=rank, world=world, reduce=hook)
-
     def run(iters):
         return ctx.mcml_full(d["start"], mcnr=True, m=C, maxiter=iters, warmup=cfg["hmc_warmup"], tol=0.0,
                              verbose=False, lambda_=cfg["lambda_"], maxsteps=cfg["max_steps"],

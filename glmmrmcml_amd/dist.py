@@ -64,13 +64,23 @@ def make_reduce_hook(group=None):
 
 def init_native_rccl(ctx, rank, world, group=None, device=None):
     """give `ctx` its own RCCL communicator (csrc/comm.hip): rank 0 makes the id, torch.distributed only carries
-    the 128 bytes to the other ranks; afterwards the library all-reduces on its own stream with no callback."""
+    the 128 bytes to the other ranks; afterwards the library all-reduces on its own stream with no callback.
+    Every step that could fail on one rank only is agreed on first (ncclCommInitRank is itself a collective: a
+    rank that skipped it would leave the others waiting).  Raises on EVERY rank or on none."""
     import torch
     import torch.distributed as dist
     from . import api
     dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
-    t = torch.zeros(128, dtype=torch.uint8, device=dev)
-    if rank == 0:
-        t.copy_(torch.tensor(list(api.rccl_unique_id()), dtype=torch.uint8))
+    ok, uid = 1, bytes(128)
+    try:
+        uid = api.rccl_unique_id()          # also proves that librccl resolves on this rank
+    except Exception as e:                  # noqa: BLE001
+        ok = 0
+        err = e
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) != 1:
+        raise RuntimeError("librccl is not usable on every rank" + ("" if ok else ": %r" % (err,)))
+    t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
     dist.broadcast(t, src=0, group=group)
     ctx.comm_init_rccl(bytes(t.cpu().tolist()), rank, world)

@@ -23,9 +23,11 @@ struct HmcState {
     DevBuf chain;               // per-chain scalars, see hmc.hip
     DevBuf partial;             // per-(row slot, chain) partial sums
     int partial_slots = 0;
+    bool cm = false;            // chain-major state (sparse ZL operator, hmc_cm.h): element (c, r) at c + r * ld
+    DevBuf cm_part, cm_acc;     // chain-major path: partial sums (ll | lp | kin | ss), accept flags
 };
 
-// ZL = Z L held as padded-CSR (ELL) rows plus its transpose in CSR: used by the sampler
+// ZL = Z L held as padded-CSR (ELL) rows plus its transpose in CSR: used by the sampler (chain-major state, hmc_cm.h)
 // instead of the dense n x Q products when Z is indicator-like and every covariance block is
 // diagonal or small, so that a row of ZL has only a few nonzeros (configs 1, 4, 5): the two
 // products are then gathers bound by HBM bandwidth, not n x Q x C GEMMs.
@@ -36,10 +38,6 @@ struct SparseZL {
     DevBuf ell_col, ell_src, ell_z, ell_val;   // n x W (column-major): column of ZL, flat index into L, Z value, value
     DevBuf csr_ptr, csr_i, csr_pos, csr_val;   // rows of ZL' : q -> (observation, position in ell_val, value)
     DevBuf row_start;                          // first column of row q of the block-diagonal L (U = L V, hmc.hip)
-    // per covariance block (all of dimension <= 16): the observations that touch it and, per observation, where in
-    // ell_val the block's effects sit (k_sp_backward_block); nblk = 0 when the structure does not apply
-    int nblk = 0, blk_dmax = 0;
-    DevBuf blk_ptr, blk_start, blk_dim, blk_obs, blk_idx;
 };
 
 // HIP-event timing of the dominant kernels, on the stream they are launched on

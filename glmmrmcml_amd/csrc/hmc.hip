@@ -22,6 +22,7 @@
 #include "glm.h"
 #include "reduce.h"
 #include "rng.h"
+#include "hmc_cm.h"
 
 namespace mcml {
 
@@ -61,19 +62,6 @@ struct EpiForwardT {
         const double mu = xb[m] + accv;
         if (store_mu) MU[m + (size_t)n * ld] = mu;
         S[m + (size_t)n * ld] = score(y[m], mu);
-    }
-    // two consecutive rows (m even) of one column with 16-byte accesses; the per-row data is loaded once per
-    // thread (row2) and reused for every chain
-    struct Row2 { d2 xb2, y2; };
-    __device__ __forceinline__ Row2 row2(int m) const {
-        return Row2{*reinterpret_cast<const d2*>(xb + m), *reinterpret_cast<const d2*>(y + m)};
-    }
-    __device__ __forceinline__ void elem2(const Row2& r, int m, int n, double a0, double a1) const {
-        d2 mu; mu.x = r.xb2.x + a0; mu.y = r.xb2.y + a1;
-        const size_t off = m + (size_t)n * ld;
-        if (store_mu) *reinterpret_cast<d2*>(MU + off) = mu;
-        d2 sc; sc.x = score(r.y2.x, mu.x); sc.y = score(r.y2.y, mu.y);
-        *reinterpret_cast<d2*>(S + off) = sc;
     }
     // Three phases -- all loads, all arithmetic, all stores -- with no use of a loaded register after the first
     // store.  The compiler's waitcnt insertion cannot count stores issued under divergent control flow, so any
@@ -140,27 +128,6 @@ struct EpiBackward {
                 UP[off] = x + en * rr;
             }
             R[off] = rr;
-        }
-    }
-    struct Row2 {};
-    __device__ __forceinline__ Row2 row2(int) const { return Row2{}; }
-    __device__ __forceinline__ void elem2(const Row2&, int m, int n, double a0, double a1) const {
-        int st = 0; double en = 0.0;
-        if (mode == 1) { st = steps[n]; en = e[n]; if (s >= st) return; }
-        const size_t off = m + (size_t)n * ld;
-        const d2 x = *reinterpret_cast<const d2*>(Xs + off);
-        d2 g; g.x = -1.0 * x.x; g.y = -1.0 * x.y;
-        g.x = g.x + post * a0; g.y = g.y + post * a1;
-        if (mode != 1 || s + 1 >= st) *reinterpret_cast<d2*>(G + off) = g;
-        if (mode == 1) {
-            d2 rr = *reinterpret_cast<const d2*>(R + off);
-            rr.x = rr.x + (en / 2) * g.x; rr.y = rr.y + (en / 2) * g.y;
-            if (s + 1 < st) {
-                rr.x = rr.x + (en / 2) * g.x; rr.y = rr.y + (en / 2) * g.y;
-                d2 up; up.x = x.x + en * rr.x; up.y = x.y + en * rr.y;
-                *reinterpret_cast<d2*>(UP + off) = up;
-            }
-            *reinterpret_cast<d2*>(R + off) = rr;
         }
     }
     // Per 16-column group: all loads (from clamped, always valid addresses), then all arithmetic into
@@ -234,208 +201,8 @@ struct EpiBackward {
 };
 
 // ------------------------------------------------------------------ sparse ZL products
-// HBM-bound gathers (configs 1, 4, 5).  The state matrices are column-major with the chain as column, so the
-// coalesced dimension is the observation / random effect: a thread owns one row of the operator, keeps that
-// row's (column, value) pairs in registers (they do not depend on the chain) and walks the chains CHUNK at a
-// time with all gathers of a chunk issued before the first use.  Neighbouring threads read neighbouring or equal
-// addresses (the observations of a cluster-period share their columns; the per-observation effect of config 5 is
-// contiguous), and every store is a full coalesced line.
-constexpr int SP_MAXW = 8;        // ELL widths up to this keep the row in registers
-constexpr int SP_CHUNK = 4;       // chains per batch of gathers
-
-// forward: acc = sum_k ZL[i, col_k] X[col_k, c]   (ELL row of observation i).
-// One workgroup = ONE chain x SP_RPT x 256 consecutive observations: every stream it touches (the state
-// column, S, MU) is one long contiguous run (16 KB), which is what the HBM controllers want -- 256-row x
-// many-chain tiles touch 2 KB runs 160 KB apart and ran at half the rate.  The ELL (column, value) pairs are
-// re-read per chain, from L2 (they are a few hundred KB).  SP_RPT independent rows per thread keep the gathers
-// in flight.
-constexpr int SP_RPT = 8;
-// A thread owns SP_RPT/2 PAIRS of adjacent observations: the ELL pairs and everything the epilogue touches move 16
-// bytes per lane (the state gathers stay scalar).
-template <class Epi>
-__global__ __launch_bounds__(256) void k_sp_forward(int n, int C, int W, const int* col, const double* val,
-                                                    const double* X, int ldx, int cpb, Epi epi)
-{
-    (void)cpb; (void)C;
-    const int c = blockIdx.y;
-    const int base = blockIdx.x * (256 * SP_RPT) + 2 * threadIdx.x;
-    const double* x = X + (size_t)c * ldx;
-    const bool vec = (n & 1) == 0;                         // column k of the ELL arrays starts 8- / 16-byte aligned
-    double a0[SP_RPT / 2], a1[SP_RPT / 2];
-#pragma unroll
-    for (int j = 0; j < SP_RPT / 2; ++j) {
-        const int i = base + 512 * j;
-        double s0 = 0.0, s1 = 0.0;
-        if (i + 1 < n && vec) {
-            for (int k = 0; k < W; ++k) {
-                const int2 cc = *reinterpret_cast<const int2*>(col + i + (size_t)k * n);
-                const d2 vv = *reinterpret_cast<const d2*>(val + i + (size_t)k * n);
-                s0 += vv.x * x[cc.x]; s1 += vv.y * x[cc.y];
-            }
-        } else if (i < n) {
-            for (int k = 0; k < W; ++k) {
-                s0 += val[i + (size_t)k * n] * x[col[i + (size_t)k * n]];
-                if (i + 1 < n) s1 += val[i + 1 + (size_t)k * n] * x[col[i + 1 + (size_t)k * n]];
-            }
-        }
-        a0[j] = s0; a1[j] = s1;
-    }
-#pragma unroll
-    for (int j = 0; j < SP_RPT / 2; ++j) {
-        const int i = base + 512 * j;
-        if (i + 1 < n) epi.elem2(epi.row2(i), i, c, a0[j], a1[j]);
-        else if (i < n) epi.elem(i, c, a0[j]);
-    }
-}
-
-// backward, short rows: acc = sum_t ZL[i_t, q] S[i_t, c]   (CSR row q of ZL'); same geometry: one chain, SP_RPT x 256
-// consecutive random effects per workgroup; `val` is the CSR-ordered copy of the values (no position
-// indirection).  (Pairs of adjacent effects per thread with 16-byte epilogue accesses, which pay in the forward
-// product, measured 25 % SLOWER here: 496 vs 401 us at config 5.)
-template <class Epi>
-__global__ __launch_bounds__(256) void k_sp_backward(int Q, int C, const int* ptr, const int* ci, const int* cp,
-                                                     const double* val, const double* S, int lds, int cpb, Epi epi)
-{
-    (void)cpb; (void)C; (void)cp;
-    const int c = blockIdx.y;
-    const int base = blockIdx.x * (256 * SP_RPT) + threadIdx.x;
-    const double* sc = S + (size_t)c * lds;
-    double acc[SP_RPT];
-#pragma unroll
-    for (int j = 0; j < SP_RPT; ++j) {
-        const int q = base + 256 * j;
-        double a = 0.0;
-        if (q < Q) {
-            const int t0 = ptr[q], t1 = ptr[q + 1];
-            for (int t = t0; t < t1; ++t) a += val[t] * sc[ci[t]];
-        }
-        acc[j] = a;
-    }
-#pragma unroll
-    for (int j = 0; j < SP_RPT; ++j) {
-        const int q = base + 256 * j;
-        if (q < Q) epi.elem(q, c, acc[j]);
-    }
-}
-
-// backward when the rows are long AND the covariance blocks are small (config 4: 40 blocks of 8 effects, 400
-// observations each): the rows of one block share their observations, so reading S once per ROW reads it
-// dim times.  One wave per (block, 4 chains): the lanes stride the block's observation list (consecutive
-// observations: coalesced), each observation's values for the block's effects sit in registers for all the
-// chains (idx[t][j] = position in ell_val of ZL[obs_t, start + j], or -1), every S element is read ONCE and
-// multiplied into DMAX accumulators; butterfly wave reduction (fixed order), then lane 8u + j finishes
-// (effect j, chain u).
-constexpr int SPB_KEEP = 8;
-template <int DMAX, class Epi>
-__global__ __launch_bounds__(256) void k_sp_backward_block(int nblk, int C, const int* bptr, const int* bstart,
-                                                           const int* bdim, const int* bobs, const int* bidx,
-                                                           const double* val, const double* S, int lds, int cpb, Epi epi)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int b = blockIdx.x;
-    const int p0 = bptr[b], p1 = bptr[b + 1], bs = bstart[b], d = bdim[b];
-    const int c0 = blockIdx.y * cpb, c1 = (c0 + cpb < C) ? c0 + cpb : C;
-    int il[SPB_KEEP]; double vl[SPB_KEEP][DMAX];
-#pragma unroll
-    for (int k = 0; k < SPB_KEEP; ++k) {
-        const int t = p0 + lane + 64 * k;
-        const bool in = t < p1;
-        il[k] = in ? bobs[t] : 0;
-#pragma unroll
-        for (int j = 0; j < DMAX; ++j) {
-            const int ix = in ? bidx[(size_t)t * DMAX + j] : -1;
-            vl[k][j] = ix >= 0 ? val[ix] : 0.0;
-        }
-    }
-    const int tk = p0 + 64 * SPB_KEEP;
-    for (int c = c0 + SP_CHUNK * w; c < c1; c += SP_CHUNK * 4) {
-        double acc[SP_CHUNK][DMAX];
-#pragma unroll
-        for (int u = 0; u < SP_CHUNK; ++u)
-#pragma unroll
-            for (int j = 0; j < DMAX; ++j) acc[u][j] = 0.0;
-#pragma unroll
-        for (int k = 0; k < SPB_KEEP; ++k) {
-            double sv[SP_CHUNK];
-#pragma unroll
-            for (int u = 0; u < SP_CHUNK; ++u) sv[u] = S[il[k] + (size_t)((c + u < c1) ? c + u : c1 - 1) * lds];
-#pragma unroll
-            for (int u = 0; u < SP_CHUNK; ++u)
-#pragma unroll
-                for (int j = 0; j < DMAX; ++j) acc[u][j] += vl[k][j] * sv[u];
-        }
-        for (int t = tk + lane; t < p1; t += 64) {           // observation lists longer than 64 x SPB_KEEP
-            const int it = bobs[t];
-#pragma unroll
-            for (int j = 0; j < DMAX; ++j) {
-                const int ix = bidx[(size_t)t * DMAX + j];
-                const double v = ix >= 0 ? val[ix] : 0.0;
-#pragma unroll
-                for (int u = 0; u < SP_CHUNK; ++u) acc[u][j] += v * S[it + (size_t)((c + u < c1) ? c + u : c1 - 1) * lds];
-            }
-        }
-        // all-lanes sums (xor butterfly: the same tree in every lane), then lane DMAX u + j takes (j, u)
-        double mine = 0.0;
-#pragma unroll
-        for (int u = 0; u < SP_CHUNK; ++u)
-#pragma unroll
-            for (int j = 0; j < DMAX; ++j) {
-                double v = acc[u][j];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-                if (lane == u * DMAX + j) mine = v;
-            }
-        if (lane < SP_CHUNK * DMAX) {
-            const int u = lane / DMAX, j = lane - u * DMAX;
-            if (j < d && c + u < c1) epi.elem(bs + j, c + u, mine);
-        }
-    }
-}
-
-// backward for long rows (tens to hundreds of observations per random effect, config 4): one wave per random
-// effect; the lanes stride the row (its observations are mostly consecutive: coalesced) and keep up to SPW_KEEP
-// (observation, value) pairs each in registers for all the chains; SP_CHUNK chains are reduced together so that
-// the shuffles of one chain overlap the loads of the next.  Fixed-order wave reduction.
-constexpr int SPW_KEEP = 8;       // 64 x 8 = 512 entries per row in registers; longer rows re-read the tail
-template <class Epi>
-__global__ __launch_bounds__(256) void k_sp_backward_wave(int Q, int C, const int* ptr, const int* ci, const int* cp,
-                                                          const double* val, const double* S, int lds, int cpb, Epi epi)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int q = blockIdx.x * 4 + w;
-    if (q >= Q) return;
-    const int t0 = ptr[q], t1 = ptr[q + 1];
-    const int c0 = blockIdx.y * cpb, c1 = (c0 + cpb < C) ? c0 + cpb : C;
-    int il[SPW_KEEP]; double vl[SPW_KEEP];
-#pragma unroll
-    for (int k = 0; k < SPW_KEEP; ++k) {
-        const int t = t0 + lane + 64 * k;
-        const bool in = t < t1;
-        il[k] = in ? ci[t] : 0;
-        vl[k] = in ? val[t] : 0.0;          // val = the CSR-ordered copy
-    }
-    const int tk = t0 + 64 * SPW_KEEP;                     // first entry not held in registers
-    for (int c = c0; c < c1; c += SP_CHUNK) {
-        double acc[SP_CHUNK];
-#pragma unroll
-        for (int u = 0; u < SP_CHUNK; ++u) {
-            const int cc = (c + u < c1) ? c + u : c1 - 1;
-            const double* sc = S + (size_t)cc * lds;
-            double a = 0.0;
-#pragma unroll
-            for (int k = 0; k < SPW_KEEP; ++k) a += vl[k] * sc[il[k]];
-            for (int t = tk + lane; t < t1; t += 64) a += val[t] * sc[ci[t]];
-            acc[u] = a;
-        }
-#pragma unroll
-        for (int u = 0; u < SP_CHUNK; ++u) acc[u] = wave_sum(acc[u]);
-        if (lane == 0) {
-#pragma unroll
-            for (int u = 0; u < SP_CHUNK; ++u)
-                if (c + u < c1) epi.elem(q, c + u, acc[u]);
-        }
-    }
-}
+// The forward / backward products of the sparse operator and the per-chain kernels that go with them live in
+// hmc_cm.h: with a sparse ZL the whole sampler state is chain-major.
 
 // U = L V for a block-diagonal L with small blocks (the sparse-ZL configurations): row q of L has entries in
 // columns start(q) .. q only.  Dense, this product is Q x Q x m (22 ms at config 5 for what is a diagonal scaling).
@@ -644,6 +411,18 @@ static int hmc_alloc(Ctx& c, int C)
 {
     HmcState& h = c.hmc;
     h.C = C;
+    h.cm = c.sp.active;
+    if (h.cm) {
+        // chain-major (hmc_cm.h): "rows" of the DevMat are the chains
+        MCML_TRY(h.V.alloc(C, c.Q)); MCML_TRY(h.R.alloc(C, c.Q)); MCML_TRY(h.UP.alloc(C, c.Q));
+        MCML_TRY(h.GRAD.alloc(C, c.Q)); MCML_TRY(h.GRADP.alloc(C, c.Q));
+        MCML_TRY(h.MU.alloc(C, c.n)); MCML_TRY(h.S.alloc(C, c.n));
+        MCML_TRY(h.chain.ensure(sizeof(double) * (size_t)round_up(C, 16) * 8));
+        const size_t nchn = (size_t)(c.n + CM_ROWS - 1) / CM_ROWS, nchq = (size_t)(c.Q + CM_ROWS - 1) / CM_ROWS;
+        MCML_TRY(h.cm_part.ensure(sizeof(double) * (nchn + 3 * nchq + 4) * (size_t)h.V.ld));
+        MCML_TRY(h.cm_acc.ensure(sizeof(int) * (size_t)round_up(C, 64)));
+        return MCML_OK;
+    }
     MCML_TRY(h.V.alloc(c.Q, C)); MCML_TRY(h.R.alloc(c.Q, C)); MCML_TRY(h.UP.alloc(c.Q, C));
     MCML_TRY(h.GRAD.alloc(c.Q, C)); MCML_TRY(h.GRADP.alloc(c.Q, C));
     MCML_TRY(h.MU.alloc(c.n, C)); MCML_TRY(h.S.alloc(c.n, C));
@@ -663,31 +442,11 @@ static bool use_dlds()
     return v == 1;
 }
 
-// chains per workgroup (a multiple of SP_CHUNK) and grid.y for the sparse products: enough workgroups to fill the
-// chip several times over (>= ~4096 of 256 threads), as few chain splits as that allows (a row's indices and
-// values are loaded once per split)
-static void sp_chain_split(int rows, int C, int& cpb, int& gy)
-{
-    const int gx = (rows + 255) / 256;
-    int want = (4096 + gx - 1) / gx;                      // splits wanted
-    if (want < 1) want = 1;
-    cpb = (C + want - 1) / want;
-    cpb = (cpb + SP_CHUNK - 1) / SP_CHUNK * SP_CHUNK;
-    if (cpb < SP_CHUNK) cpb = SP_CHUNK;
-    gy = (C + cpb - 1) / cpb;
-}
-
 // MU = xb + ZL * X ; S = score
 template <class Epi>
 static int hmc_forward_launch(Ctx& c, const double* X, int ldx, const Epi& epi)
 {
     HmcState& h = c.hmc;
-    if (c.sp.active) {
-        const int cpb = 1, gy = h.C;
-        hipLaunchKernelGGL((k_sp_forward<Epi>), dim3((c.n + 256 * SP_RPT - 1) / (256 * SP_RPT), gy), dim3(256), 0, c.stream, c.n, h.C,
-                           c.sp.W, c.sp.ell_col.as<int>(), c.sp.ell_val.d(), X, ldx, cpb, epi);
-        return (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
-    }
     if (c.band_fwd && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
         return launch_gemm_band(c.stream, c.plan_fwd, h.C, c.ZL.d(), c.ZL.ld, X, ldx, epi);
     if (use_dlds() && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
@@ -700,7 +459,17 @@ static int hmc_forward(Ctx& c, const double* X, int ldx, double var_par, bool st
     HmcState& h = c.hmc;
     const int slot = c.prof.begin(c.stream, 0, chain);
     int rc;
-    if (c.flink == 12)      // beta/logit: the digamma score is its own instantiation (glm.h)
+    if (h.cm) {
+        const int rpw = CM_FR;
+        dim3 grid((c.n + 4 * rpw - 1) / (4 * rpw), (h.C + 63) / 64);
+        if (c.flink == 12)
+            hipLaunchKernelGGL((k_cm_forward<true>), grid, dim3(256), 0, c.stream, c.n, h.C, h.V.ld, c.sp.W, c.sp.ell_col.as<int>(),
+                               c.sp.ell_val.d(), X, c.xb.d(), c.y.d(), c.flink, var_par, store_mu ? 1 : 0, h.MU.d(), h.S.d(), rpw);
+        else
+            hipLaunchKernelGGL((k_cm_forward<false>), grid, dim3(256), 0, c.stream, c.n, h.C, h.V.ld, c.sp.W, c.sp.ell_col.as<int>(),
+                               c.sp.ell_val.d(), X, c.xb.d(), c.y.d(), c.flink, var_par, store_mu ? 1 : 0, h.MU.d(), h.S.d(), rpw);
+        rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
+    } else if (c.flink == 12)      // beta/logit: the digamma score is its own instantiation (glm.h)
         rc = hmc_forward_launch(c, X, ldx, EpiForwardT<true>{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink,
                                                              store_mu ? 1 : 0, var_par});
     else
@@ -717,36 +486,23 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
     EpiBackward epi{Xs, G, h.R.d(), h.UP.d(), h.V.ld, ca.e, ca.steps, s, glm_score_post(var_par, c.flink), mode};
     const int slot = c.prof.begin(c.stream, 1, chain);
     int rc;
-    static const bool use_block = getenv("GLMMR_MCML_SPB") != nullptr && atoi(getenv("GLMMR_MCML_SPB")) != 0;   // measured 90 vs 78 us (wave kernel) at config 4: off
-    if (c.sp.active && c.sp.nnz >= 24L * c.Q && c.sp.nblk > 0 && use_block) {
-        // long rows in small covariance blocks: a wave per (block, 4 chains), S read once
-        int cpb = (h.C * c.sp.nblk + 4095) / 4096;                 // ~4096 waves in all
-        cpb = (cpb + 4 * SP_CHUNK - 1) / (4 * SP_CHUNK) * (4 * SP_CHUNK);
-        const int gy = (h.C + cpb - 1) / cpb;
-        if (c.sp.blk_dmax <= 8)
-            hipLaunchKernelGGL((k_sp_backward_block<8, EpiBackward>), dim3(c.sp.nblk, gy), dim3(256), 0, c.stream, c.sp.nblk, h.C,
-                               c.sp.blk_ptr.as<int>(), c.sp.blk_start.as<int>(), c.sp.blk_dim.as<int>(), c.sp.blk_obs.as<int>(),
-                               c.sp.blk_idx.as<int>(), c.sp.ell_val.d(), h.S.d(), h.S.ld, cpb, epi);
-        else
-            hipLaunchKernelGGL((k_sp_backward_block<16, EpiBackward>), dim3(c.sp.nblk, gy), dim3(256), 0, c.stream, c.sp.nblk, h.C,
-                               c.sp.blk_ptr.as<int>(), c.sp.blk_start.as<int>(), c.sp.blk_dim.as<int>(), c.sp.blk_obs.as<int>(),
-                               c.sp.blk_idx.as<int>(), c.sp.ell_val.d(), h.S.d(), h.S.ld, cpb, epi);
+    if (h.cm) {
+        if (c.sp.nnz >= 24L * c.Q) {          // long rows: a workgroup per (random effect, 64 chains)
+            hipLaunchKernelGGL(k_cm_backward_long, dim3(c.Q, (h.C + 63) / 64), dim3(256), 0, c.stream, c.Q, h.C, h.V.ld,
+                               c.sp.csr_ptr.as<int>(), c.sp.csr_i.as<int>(), c.sp.csr_val.d(), h.S.d(), Xs, G, h.R.d(), h.UP.d(),
+                               ca.e, ca.steps, s, glm_score_post(var_par, c.flink), mode);
+        } else {
+            const int rpw = 2;
+            dim3 grid((c.Q + 4 * rpw - 1) / (4 * rpw), (h.C + 63) / 64);
+            hipLaunchKernelGGL(k_cm_backward, grid, dim3(256), 0, c.stream, c.Q, h.C, h.V.ld, c.sp.csr_ptr.as<int>(),
+                               c.sp.csr_i.as<int>(), c.sp.csr_val.d(), h.S.d(), Xs, G, h.R.d(), h.UP.d(), ca.e, ca.steps, s,
+                               glm_score_post(var_par, c.flink), mode, rpw);
+        }
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
-    } else if (c.sp.active && c.sp.nnz >= 24L * c.Q) {
-        // long rows: a wave per random effect, 4 per workgroup; chains split so that the grid has >= ~2000 workgroups
-        int cpb, gy;
-        sp_chain_split(64 * ((c.Q + 3) / 4) * 4, h.C, cpb, gy);
-        hipLaunchKernelGGL((k_sp_backward_wave<EpiBackward>), dim3((c.Q + 3) / 4, gy), dim3(256), 0, c.stream, c.Q, h.C,
-                           c.sp.csr_ptr.as<int>(), c.sp.csr_i.as<int>(), c.sp.csr_pos.as<int>(), c.sp.csr_val.d(),
-                           h.S.d(), h.S.ld, cpb, epi);
-        rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
-    } else if (c.sp.active) {
-        const int cpb = 1, gy = h.C;
-        hipLaunchKernelGGL((k_sp_backward<EpiBackward>), dim3((c.Q + 256 * SP_RPT - 1) / (256 * SP_RPT), gy), dim3(256), 0, c.stream, c.Q, h.C,
-                           c.sp.csr_ptr.as<int>(), c.sp.csr_i.as<int>(), c.sp.csr_pos.as<int>(), c.sp.csr_val.d(),
-                           h.S.d(), h.S.ld, cpb, epi);
-        rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
-    } else if (c.band_bwd && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
+        c.prof.end(c.stream, slot);
+        return rc;
+    }
+    if (c.band_bwd && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
         rc = launch_gemm_band(c.stream, c.plan_bwd, h.C, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
     else if (use_dlds() && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
         rc = launch_gemm_dlds(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
@@ -756,12 +512,44 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
     return rc;
 }
 
+// ---- chain-major helpers (sparse ZL operator, hmc_cm.h) ----
+static CmChain cm_chain(const ChainArrays& a)
+{
+    return CmChain{a.e, a.ebar, a.H, a.lpcur, a.K0, a.steps, a.acc, a.gen, a.leap};
+}
+struct CmParts { double *ll, *lp, *kin, *ss; int nchn, nchq, ldp; };
+static CmParts cm_parts(const Ctx& c)
+{
+    const HmcState& h = c.hmc;
+    CmParts p;
+    p.nchn = (c.n + CM_ROWS - 1) / CM_ROWS; p.nchq = (c.Q + CM_ROWS - 1) / CM_ROWS; p.ldp = h.V.ld;
+    p.ll = h.cm_part.d(); p.lp = p.ll + (size_t)p.nchn * p.ldp; p.kin = p.lp + (size_t)p.nchq * p.ldp;
+    p.ss = p.kin + (size_t)p.nchq * p.ldp;
+    return p;
+}
+// partial sums of log f(y | MU) + log N(X; 0, 1) (+ R^2) of every chain
+static int cm_logprob_partials(Ctx& c, const double* X, const double* R, double var_par)
+{
+    HmcState& h = c.hmc;
+    const CmParts p = cm_parts(c);
+    hipLaunchKernelGGL(k_cm_logprob_partials, dim3((h.C + 63) / 64, p.nchn + p.nchq), dim3(256), 0, c.stream, h.MU.d(), X, R,
+                       h.V.ld, c.n, c.Q, h.C, c.y.d(), var_par, c.flink, p.nchn, p.ll, p.lp, p.kin, p.ldp);
+    MCML_HIP(hipGetLastError());
+    return MCML_OK;
+}
+
 // log_prob and log_grad of every column of the current V
 static int hmc_eval_state(Ctx& c, double var_par)
 {
     HmcState& h = c.hmc;
     ChainArrays ca = chain_arrays(h);
     MCML_TRY(hmc_forward(c, h.V.d(), h.V.ld, var_par));
+    if (h.cm) {
+        const CmParts p = cm_parts(c);
+        MCML_TRY(cm_logprob_partials(c, h.V.d(), nullptr, var_par));
+        hipLaunchKernelGGL(k_cm_lp0_fin, dim3((h.C + 255) / 256), dim3(256), 0, c.stream, p.ll, p.lp, p.nchn, p.nchq, p.ldp,
+                           h.C, ca.lpcur);
+    } else
     hipLaunchKernelGGL(k_hmc_lp0, dim3(h.C), dim3(256), 0, c.stream, h.MU.d(), h.MU.ld, c.n, h.V.d(), h.V.ld, c.Q,
                        c.y.d(), var_par, c.flink, ca.lpcur);
     MCML_HIP(hipGetLastError());
@@ -804,12 +592,23 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
     if (flags_out) MCML_TRY(d_flags.ensure((size_t)C * total));
     if (probs_out) MCML_TRY(d_probs.ensure(sizeof(double) * (size_t)C * total));
 
+    const int nchq = (Q + CM_ROWS - 1) / CM_ROWS;
+    auto store = [&](int stride, int col) {
+        if (h.cm)      // SAMP[k + (c * stride + col) * lds] = V[c + k * ldc]
+            hipLaunchKernelGGL(k_cm_transpose, dim3((Q + 31) / 32, (C + 31) / 32), dim3(256), 0, c.stream, h.V.d(), h.V.ld, Q, C,
+                               samp.d(), (size_t)samp.ld, (size_t)(stride > 0 ? stride : 1), col);
+        else
+            hipLaunchKernelGGL(k_hmc_store, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.V.ld, Q, samp.d(), samp.ld, stride, col);
+    };
+    if (h.cm)
+        hipLaunchKernelGGL(k_cm_init, dim3((C + 63) / 64, nchq), dim3(256), 0, c.stream, h.V.d(), h.V.ld, Q, C, cm_chain(ca), seed,
+                           (uint32_t)o->chain_offset, iter_idx, p_init);
+    else
     hipLaunchKernelGGL(k_hmc_init, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.V.ld, Q, ca, seed,
                        (uint32_t)o->chain_offset, iter_idx, p_init);
     MCML_HIP(hipGetLastError());
     MCML_TRY(hmc_eval_state(c, var_par));
-    if (C == 1 && o->warmup == 0)
-        hipLaunchKernelGGL(k_hmc_store, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.V.ld, Q, samp.d(), samp.ld, 0, 0);
+    if (C == 1 && o->warmup == 0) store(0, 0);
 
     int* d_maxs = c.scalars.as<int>() + 34;
     // The number of leapfrog iterations to launch is the largest step count over the chains, a device
@@ -832,6 +631,14 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
     } ring_guard{h_ring, ring_ev, RING, c.stream};
     int seen_maxs = -1;                         // latest step count actually observed
     for (int it = 0; it < total; ++it) {
+        if (h.cm) {
+            const CmParts p = cm_parts(c);
+            hipLaunchKernelGGL(k_cm_propose, dim3((C + 63) / 64, p.nchq), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(),
+                               h.UP.d(), h.V.ld, Q, C, cm_chain(ca), seed, (uint32_t)o->chain_offset, iter_idx, it, p_mom,
+                               p.ss, p.ldp);
+            hipLaunchKernelGGL(k_cm_propose_fin, dim3((C + 255) / 256), dim3(256), 0, c.stream, p.ss, p.nchq, p.ldp, C,
+                               cm_chain(ca), o->lambda, o->max_steps);
+        } else
         hipLaunchKernelGGL(k_hmc_propose, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(), h.UP.d(),
                            h.V.ld, Q, ca, o->lambda, o->max_steps, seed, (uint32_t)o->chain_offset, iter_idx, it,
                            p_mom, C);
@@ -860,6 +667,16 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         }
         c.prof.unchain();
         const int adapt = (it < o->warmup) && (it < o->adapt);     // mhmcmc.h:131-136
+        if (h.cm) {
+            const CmParts p = cm_parts(c);
+            MCML_TRY(cm_logprob_partials(c, h.UP.d(), h.R.d(), var_par));
+            hipLaunchKernelGGL(k_cm_accept_fin, dim3((C + 255) / 256), dim3(256), 0, c.stream, p.ll, p.lp, p.kin, p.nchn, p.nchq,
+                               p.ldp, C, cm_chain(ca), o->target_accept, adapt, it,
+                               flags_out ? d_flags.as<uint8_t>() : nullptr, probs_out ? d_probs.d() : nullptr,
+                               h.cm_acc.as<int>());
+            hipLaunchKernelGGL(k_cm_commit, dim3((C + 63) / 64, p.nchq), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.UP.d(),
+                               h.GRADP.d(), h.V.ld, Q, C, h.cm_acc.as<int>());
+        } else
         hipLaunchKernelGGL(k_hmc_accept, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(), h.UP.d(),
                            h.GRADP.d(), h.V.ld, Q, h.MU.d(), h.MU.ld, n, c.y.d(), var_par, c.flink, ca,
                            o->target_accept, adapt, it, C, flags_out ? d_flags.as<uint8_t>() : nullptr,
@@ -869,9 +686,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
             if (it == o->warmup - 1) col = 0;                      // samples.col(0) = u_, :142
             else if (it >= o->warmup) col = it - o->warmup + 1;    // samples.col(i+1) = u_, :147
         } else if (it >= o->warmup) { col = it - o->warmup; stride = d; }
-        if (col >= 0)
-            hipLaunchKernelGGL(k_hmc_store, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.V.ld, Q, samp.d(), samp.ld,
-                               stride, col);
+        if (col >= 0) store(stride, col);
         MCML_HIP(hipGetLastError());
     }
     // return (L * samples)  (mhmcmc.h:155)
@@ -913,10 +728,27 @@ int hmc_dbg_log_prob_grad(Ctx& c, const double* beta, double var_par, const doub
     MCML_TRY(model_update_beta(c, beta));
     MCML_TRY(hmc_alloc(c, ncols));
     HmcState& h = c.hmc;
+    ChainArrays ca = chain_arrays(h);
+    if (h.cm) {
+        DevMat tmp;                                   // Q x ncols column-major staging
+        MCML_TRY(tmp.alloc(c.Q, ncols));
+        MCML_HIP(hipMemcpy2DAsync(tmp.d(), sizeof(double) * tmp.ld, V, sizeof(double) * c.Q, sizeof(double) * c.Q,
+                                  ncols, hipMemcpyHostToDevice, c.stream));
+        // V[c + q * ldc] = tmp[q + c * ld]
+        hipLaunchKernelGGL(k_cm_transpose, dim3((ncols + 31) / 32, (c.Q + 31) / 32), dim3(256), 0, c.stream, tmp.d(), tmp.ld,
+                           ncols, c.Q, h.V.d(), (size_t)h.V.ld, (size_t)1, 0);
+        MCML_HIP(hipGetLastError());
+        MCML_TRY(hmc_eval_state(c, var_par));
+        hipLaunchKernelGGL(k_cm_transpose, dim3((c.Q + 31) / 32, (ncols + 31) / 32), dim3(256), 0, c.stream, h.GRAD.d(), h.GRAD.ld,
+                           c.Q, ncols, tmp.d(), (size_t)tmp.ld, (size_t)1, 0);
+        MCML_HIP(hipGetLastError());
+        MCML_HIP(hipMemcpyAsync(lp, ca.lpcur, sizeof(double) * ncols, hipMemcpyDeviceToHost, c.stream));
+        MCML_TRY(download_matrix(G, c.Q, tmp.d(), tmp.ld, c.Q, ncols, c.stream));
+        return c.sync();                              // tmp goes out of scope
+    }
     MCML_HIP(hipMemcpy2DAsync(h.V.d(), sizeof(double) * h.V.ld, V, sizeof(double) * c.Q, sizeof(double) * c.Q,
                               ncols, hipMemcpyHostToDevice, c.stream));
     MCML_TRY(hmc_eval_state(c, var_par));
-    ChainArrays ca = chain_arrays(h);
     MCML_HIP(hipMemcpyAsync(lp, ca.lpcur, sizeof(double) * ncols, hipMemcpyDeviceToHost, c.stream));
     return download_matrix(G, c.Q, h.GRAD.d(), h.GRAD.ld, c.Q, ncols, c.stream);
 }

@@ -1,0 +1,348 @@
+// hmc_cm.h -- the sampler's kernels for the SPARSE ZL operator (configs 1, 4, 5) with the HMC state stored
+// CHAIN-MAJOR: element (chain c, row r) of V, R, UP, GRAD, GRADP (rows = random effects) and of MU, S (rows =
+// observations) lives at  c + r * ldc,  64 consecutive chains = one wave's 512 contiguous bytes.
+//
+// Why: the sparse products are HBM-bound gathers.  With the dense layout (chain = column) a thread owns a row and
+// every lane carries its own row's pointers, indices and values: 11 load instructions per element of which 3 are HBM
+// streams (profiles/r02_cfg5_*: 2.1-3.0 TB/s).  Chain-major, a wave is 64 chains of ONE row: the row's metadata is
+// wave-uniform (scalar loads), every state access is one coalesced 512-byte line, and the sums over a row's entries
+// need no cross-lane reduction.  Measured on the config-5 backward shape (scripts/sp_proto.hip): 184 us = 4.8 TB/s
+// algorithmic against 401 us.
+//
+// Per-chain sums (log-density, kinetic energy) are two-stage with a fixed order: a workgroup = 64 chains x 4 waves
+// owns SUM_ROWS consecutive rows and leaves one partial per (row chunk, chain); the finishing kernels add the
+// chunks in order.  The RNG is keyed by (element, GLOBAL chain, proposal, tag) exactly as in the dense path, so
+// the momenta and accept streams are bit-identical to it and to the oracle.
+#pragma once
+#include "ctx.h"
+#include "glm.h"
+#include "rng.h"
+
+namespace mcml {
+
+constexpr int CM_ROWS = 64;       // rows per workgroup in the elementwise / partial-sum kernels (16 per wave)
+
+struct CmChain {                  // the per-chain scalars of hmc.hip::ChainArrays
+    double *e, *ebar, *H, *lpcur, *K0;
+    int *steps, *acc;
+    uint32_t* gen;
+    long long* leap;
+};
+
+// ---- products -------------------------------------------------------------------------------------------------
+// forward: MU[c, i] = xb_i + sum_k val_k X[c, col_k] ; S = score(y_i, MU)      (ELL row of observation i)
+// a wave owns CM_FR consecutive observations: the k loop is outermost so that CM_FR independent gathers are in
+// flight per iteration, then CM_FR independent scores and stores
+constexpr int CM_FR = 4;       // 8 measured slower (152 vs 121 us at config 5)
+template <bool BETA>
+__global__ __launch_bounds__(256) void k_cm_forward(int n, int C, int ldc, int W, const int* col, const double* val,
+                                                    const double* X, const double* xb, const double* y, int flink,
+                                                    double var_par, int store_mu, double* MU, double* S, int rpw)
+{
+    (void)rpw;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    const int i0 = (blockIdx.x * 4 + w) * CM_FR;
+    if (c >= C || i0 >= n) return;
+    double acc[CM_FR];
+#pragma unroll
+    for (int r = 0; r < CM_FR; ++r) acc[r] = 0.0;
+    for (int k = 0; k < W; ++k) {
+        double xv[CM_FR], vv[CM_FR];
+#pragma unroll
+        for (int r = 0; r < CM_FR; ++r) {
+            const int i = (i0 + r < n) ? i0 + r : n - 1;
+            const int q = __builtin_amdgcn_readfirstlane(col[i + (size_t)k * n]);
+            vv[r] = val[i + (size_t)k * n];                            // uniform address: one value for the wave
+            xv[r] = X[c + (size_t)q * ldc];
+        }
+#pragma unroll
+        for (int r = 0; r < CM_FR; ++r) acc[r] += vv[r] * xv[r];
+    }
+#pragma unroll
+    for (int r = 0; r < CM_FR; ++r) {
+        const int i = i0 + r;
+        if (i < n) {
+            const double mu = xb[i] + acc[r];
+            const size_t off = c + (size_t)i * ldc;
+            if (store_mu) MU[off] = mu;
+            S[off] = BETA ? glm_score_beta(y[i], mu, var_par) : glm_score(y[i], mu, flink);
+        }
+    }
+}
+
+// backward: g = -x + post * sum_t val_t S[c, i_t]  (CSR row q of ZL'), then the leapfrog update of hmc.hip::EpiBackward
+__global__ __launch_bounds__(256) void k_cm_backward(int Q, int C, int ldc, const int* ptr, const int* ci,
+                                                     const double* val, const double* S, const double* Xs, double* G,
+                                                     double* R, double* UP, const double* e, const int* steps, int s,
+                                                     double post, int mode, int rpw)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    const int q0 = (blockIdx.x * 4 + w) * rpw;
+    if (c >= C) return;
+    int st = 0; double en = 0.0;
+    if (mode == 1) { st = steps[c]; en = e[c]; }
+    for (int q = q0; q < q0 + rpw && q < Q; ++q) {
+        const int t0 = __builtin_amdgcn_readfirstlane(ptr[q]), t1 = __builtin_amdgcn_readfirstlane(ptr[q + 1]);
+        double acc = 0.0;
+        int t = t0;
+        for (; t + 4 <= t1; t += 4) {                                  // four gathers in flight
+            const int i0 = __builtin_amdgcn_readfirstlane(ci[t]), i1 = __builtin_amdgcn_readfirstlane(ci[t + 1]);
+            const int i2 = __builtin_amdgcn_readfirstlane(ci[t + 2]), i3 = __builtin_amdgcn_readfirstlane(ci[t + 3]);
+            const double s0 = S[c + (size_t)i0 * ldc], s1 = S[c + (size_t)i1 * ldc];
+            const double s2 = S[c + (size_t)i2 * ldc], s3 = S[c + (size_t)i3 * ldc];
+            acc += val[t] * s0; acc += val[t + 1] * s1; acc += val[t + 2] * s2; acc += val[t + 3] * s3;
+        }
+        for (; t < t1; ++t) acc += val[t] * S[c + (size_t)__builtin_amdgcn_readfirstlane(ci[t]) * ldc];
+        if (mode == 1 && s >= st) continue;
+        const size_t off = c + (size_t)q * ldc;
+        const double x = Xs[off];
+        double g = -1.0 * x;
+        g = g + post * acc;
+        if (mode != 1 || s + 1 >= st) G[off] = g;                      // mid-trajectory gradients are never read
+        if (mode == 1) {
+            double rr = R[off];
+            rr = rr + (en / 2) * g;
+            if (s + 1 < st) { rr = rr + (en / 2) * g; UP[off] = x + en * rr; }
+            R[off] = rr;
+        }
+    }
+}
+
+// backward for long rows (tens to hundreds of observations per random effect, config 4): a workgroup = ONE random
+// effect x 64 chains; its four waves split the row's entries (contiguous quarters), eight gathers in flight each; the
+// four partial sums are added in wave order through LDS (fixed order) and wave 0 applies the leapfrog update
+__global__ __launch_bounds__(256) void k_cm_backward_long(int Q, int C, int ldc, const int* ptr, const int* ci,
+                                                          const double* val, const double* S, const double* Xs, double* G,
+                                                          double* R, double* UP, const double* e, const int* steps, int s,
+                                                          double post, int mode)
+{
+    __shared__ double sh[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x;
+    const int c = blockIdx.y * 64 + lane;
+    const bool cin = c < C;
+    const int cc = cin ? c : 0;
+    const int t0 = __builtin_amdgcn_readfirstlane(ptr[q]), t1 = __builtin_amdgcn_readfirstlane(ptr[q + 1]);
+    const int len = t1 - t0, per = (len + 3) >> 2;
+    const int a = t0 + w * per, b = (a + per < t1) ? a + per : t1;
+    double acc = 0.0;
+    int t = a;
+    for (; t + 8 <= b; t += 8) {
+        double sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sv[u] = S[cc + (size_t)__builtin_amdgcn_readfirstlane(ci[t + u]) * ldc];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += val[t + u] * sv[u];
+    }
+    for (; t < b; ++t) acc += val[t] * S[cc + (size_t)__builtin_amdgcn_readfirstlane(ci[t]) * ldc];
+    sh[w][lane] = acc;
+    __syncthreads();
+    if (w != 0 || !cin) return;
+    acc = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+    int st = 0; double en = 0.0;
+    if (mode == 1) { st = steps[c]; en = e[c]; if (s >= st) return; }
+    const size_t off = c + (size_t)q * ldc;
+    const double x = Xs[off];
+    double g = -1.0 * x;
+    g = g + post * acc;
+    if (mode != 1 || s + 1 >= st) G[off] = g;
+    if (mode == 1) {
+        double rr = R[off];
+        rr = rr + (en / 2) * g;
+        if (s + 1 < st) { rr = rr + (en / 2) * g; UP[off] = x + en * rr; }
+        R[off] = rr;
+    }
+}
+
+// (A block-at-a-time variant -- one workgroup per covariance block, S read once, the block's effects in DMAX
+// accumulators with wave-uniform values -- measured 121 us against 72 us for the kernel above at config 4: the
+// scalar index loads per observation cost more than the re-reads of S from L2 save.)
+
+// ---- per-chain kernels -------------------------------------------------------------------------------------------
+// grid (chains / 64, row chunks of CM_ROWS); wave w of a workgroup takes rows w, w + 4, ... of the chunk and the four
+// waves' sums are added in wave order through LDS: one partial per (chunk, chain)
+__device__ __forceinline__ void cm_block_partial(double v, double* part, int chunk, int ldp, int c, bool cin)
+{
+    __shared__ double sh[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    sh[w][lane] = v;
+    __syncthreads();
+    if (w == 0 && cin) part[(size_t)chunk * ldp + c] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_cm_init(double* V, int ldc, int Q, int C, CmChain ca, uint64_t seed,
+                                                 uint32_t chain_offset, uint32_t iter_idx, const double* inj_init)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    if (c >= C) return;
+    const uint32_t gid = chain_offset + (uint32_t)c;
+    const int q0 = blockIdx.y * CM_ROWS;
+    for (int q = q0 + w; q < q0 + CM_ROWS && q < Q; q += 4)
+        V[c + (size_t)q * ldc] = inj_init ? inj_init[q + (size_t)c * Q]
+                                          : rng_normal(seed, (uint32_t)q, gid, 0u, 16u * iter_idx + 0u);
+    if (blockIdx.y == 0 && w == 0) {                              // initialise_u, mhmcmc.h:47-59
+        ca.e[c] = 0.001; ca.ebar[c] = 1.0; ca.H[c] = 0.0; ca.acc[c] = 0; ca.leap[c] = 0;
+        ca.gen[c] = chain_minstd_seed(seed, gid, iter_idx);
+        ca.steps[c] = 1;
+    }
+}
+
+// partial sums of log f(y_i | MU[c,i]) over observation chunks [0, nchunk_n) and of log N(X[c,q]; 0, 1) (+ R[c,q]^2
+// when R is given) over random-effect chunks: part_ll / part_lp / part_kin, ld = ldp
+__global__ __launch_bounds__(256) void k_cm_logprob_partials(const double* MU, const double* X, const double* R, int ldc,
+                                                             int n, int Q, int C, const double* y, double var_par,
+                                                             int flink, int nchunk_n, double* part_ll, double* part_lp,
+                                                             double* part_kin, int ldp)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool cin = c < C;
+    const int cc = cin ? c : 0;
+    if ((int)blockIdx.y < nchunk_n) {
+        const int i0 = blockIdx.y * CM_ROWS;
+        double ll = 0.0;
+        for (int i = i0 + w; i < i0 + CM_ROWS && i < n; i += 4) ll += glm_logpdf(y[i], MU[cc + (size_t)i * ldc], var_par, flink);
+        cm_block_partial(ll, part_ll, blockIdx.y, ldp, c, cin);
+    } else {
+        const int ch = blockIdx.y - nchunk_n, q0 = ch * CM_ROWS;
+        double lp = 0.0, kin = 0.0;
+        for (int q = q0 + w; q < q0 + CM_ROWS && q < Q; q += 4) {
+            lp += glm_logpdf(X[cc + (size_t)q * ldc], 0, 1, 7);
+            if (R) { const double r = R[cc + (size_t)q * ldc]; kin += r * r; }
+        }
+        cm_block_partial(lp, part_lp, ch, ldp, c, cin);
+        if (R) cm_block_partial(kin, part_kin, ch, ldp, c, cin);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cm_lp0_fin(const double* part_ll, const double* part_lp, int nchunk_n,
+                                                    int nchunk_q, int ldp, int C, double* lpcur)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nchunk_n; ++k) a += part_ll[(size_t)k * ldp + c];
+    for (int k = 0; k < nchunk_q; ++k) b += part_lp[(size_t)k * ldp + c];
+    lpcur[c] = a + b;                                             // ll.sum() + lp.sum(), mcmlmodel.h:151
+}
+
+// new_proposal, first part (mhmcmc.h:62-75): momentum, first half step + position; partial sums of r^2
+__global__ __launch_bounds__(256) void k_cm_propose(const double* V, const double* GRAD, double* R, double* UP, int ldc,
+                                                    int Q, int C, CmChain ca, uint64_t seed, uint32_t chain_offset,
+                                                    uint32_t iter_idx, int it, const double* inj_mom, double* part_ss,
+                                                    int ldp)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool cin = c < C;
+    const int cc = cin ? c : 0;
+    const uint32_t gid = chain_offset + (uint32_t)cc;
+    const double e = ca.e[cc];
+    const int q0 = blockIdx.y * CM_ROWS;
+    double ss = 0.0;
+    if (cin)
+        for (int q = q0 + w; q < q0 + CM_ROWS && q < Q; q += 4) {
+            const size_t off = c + (size_t)q * ldc;
+            double r = inj_mom ? inj_mom[q + ((size_t)it * C + c) * Q]
+                               : rng_normal(seed, (uint32_t)q, gid, (uint32_t)it, 16u * iter_idx + 2u);
+            ss += r * r;
+            const double g = GRAD[off], v = V[off];
+            r = r + (e / 2) * g;
+            R[off] = r;
+            UP[off] = v + e * r;
+        }
+    cm_block_partial(ss, part_ss, blockIdx.y, ldp, c, cin);
+}
+
+__global__ __launch_bounds__(256) void k_cm_propose_fin(const double* part_ss, int nchunk_q, int ldp, int C, CmChain ca,
+                                                        double lambda, int max_steps)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double tot = 0.0;
+    for (int k = 0; k < nchunk_q; ++k) tot += part_ss[(size_t)k * ldp + c];
+    ca.K0[c] = 0.5 * tot;
+    double st = round(lambda / ca.e[c]);                          // mhmcmc.h:69-70
+    if (!(st >= 1.0)) st = 1.0;
+    if (st > (double)max_steps) st = (double)max_steps;
+    ca.steps[c] = (int)st;
+    ca.leap[c] += (long long)st;
+}
+
+// new_proposal, second part (mhmcmc.h:80-117): the decision of every chain
+__global__ __launch_bounds__(256) void k_cm_accept_fin(const double* part_ll, const double* part_lp, const double* part_kin,
+                                                       int nchunk_n, int nchunk_q, int ldp, int C, CmChain ca,
+                                                       double target_accept, int adapt, int it, uint8_t* flags,
+                                                       double* probs, int* accflag)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0, kin = 0.0;
+    for (int k = 0; k < nchunk_n; ++k) a += part_ll[(size_t)k * ldp + c];
+    for (int k = 0; k < nchunk_q; ++k) { b += part_lp[(size_t)k * ldp + c]; kin += part_kin[(size_t)k * ldp + c]; }
+    const double l2 = a + b;
+    const double lprt = 0.5 * kin, lpr = ca.K0[c], l1 = ca.lpcur[c];
+    const double prob = fmin(1.0, exp(-l1 + lpr + l2 - lprt));
+    uint32_t g = ca.gen[c];
+    const double runif = minstd_canonical(g);
+    ca.gen[c] = g;
+    const int acc = runif < prob;
+    accflag[c] = acc;
+    if (acc) { ca.lpcur[c] = l2; ca.acc[c] += 1; }
+    if (flags) flags[c + (size_t)it * C] = (uint8_t)acc;
+    if (probs) probs[c + (size_t)it * C] = prob;
+    if (adapt) {                                                  // mhmcmc.h:107-114
+        const int iter = it + 1;
+        const double f1 = 1.0 / (iter + 10);
+        const double H = (1 - f1) * ca.H[c] + f1 * (target_accept - prob);
+        ca.H[c] = H;
+        const double loge = -4.60517 - (sqrt((double)iter / 0.05)) * H;
+        const double powm = pow((double)iter, -0.75);
+        const double logbare = powm * loge + (1 - powm) * log(ca.ebar[c]);
+        ca.e[c] = exp(loge);
+        ca.ebar[c] = exp(logbare);
+    } else {
+        ca.e[c] = ca.ebar[c];                                     // :116
+    }
+}
+
+// accepted chains: V <- UP, GRAD <- GRADP
+__global__ __launch_bounds__(256) void k_cm_commit(double* V, double* GRAD, const double* UP, const double* GRADP,
+                                                   int ldc, int Q, int C, const int* accflag)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    if (c >= C || !accflag[c]) return;
+    const int q0 = blockIdx.y * CM_ROWS;
+    for (int q = q0 + w; q < q0 + CM_ROWS && q < Q; q += 4) {
+        const size_t off = c + (size_t)q * ldc;
+        V[off] = UP[off]; GRAD[off] = GRADP[off];
+    }
+}
+
+// B (rows x cols, column-major, ldb) <- A' where A is chain-major (A[c + r * ldc], c < cols_src = rows of B ...):
+// generic 32 x 32 LDS transpose: OUT[i + j * ldo] = IN[j + i * ldi], i < ni, j < nj
+__global__ __launch_bounds__(256) void k_cm_transpose(const double* IN, int ldi, int ni, int nj, double* OUT, size_t ldo,
+                                                      size_t out_col_stride_mult, int out_col_offset)
+{
+    // out column index of source index j: j * out_col_stride_mult + out_col_offset (used to interleave the draws of
+    // several chains in the sample matrix)
+    __shared__ double tile[32][33];
+    const int bi = blockIdx.x * 32, bj = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int j = bj + tx, i = bi + r;
+        tile[r][tx] = (i < ni && j < nj) ? IN[j + (size_t)i * ldi] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int i = bi + tx, j = bj + r;
+        if (i < ni && j < nj) OUT[i + ((size_t)j * out_col_stride_mult + out_col_offset) * ldo] = tile[tx][r];
+    }
+}
+
+}  // namespace mcml

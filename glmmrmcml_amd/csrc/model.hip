@@ -200,53 +200,6 @@ static int sparse_zl_setup(Ctx& c)
     MCML_HIP(hipMemcpyAsync(sp.csr_ptr.p, ptr.data(), sizeof(int) * (size_t)(Q + 1), hipMemcpyHostToDevice, c.stream));
     MCML_HIP(hipMemcpyAsync(sp.csr_i.p, ci.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c.stream));
     MCML_HIP(hipMemcpyAsync(sp.csr_pos.p, cp.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c.stream));
-    // ---- block view for the long-row backward product: every covariance block of dimension <= 16
-    sp.nblk = 0; sp.blk_dmax = 0;
-    {
-        int dmax = 0;
-        for (int b = 0; b < c.cov.B; ++b) dmax = std::max(dmax, c.cov.blocks[b].dim);
-        if (dmax >= 2 && dmax <= 16) {
-            const int DM = dmax <= 8 ? 8 : 16, B = c.cov.B;
-            std::vector<std::vector<int>> obs(B);
-            std::vector<int> last(B, -1);
-            for (int i = 0; i < n; ++i)
-                for (int w = 0; w < width[i]; ++w) {
-                    const int b = blk_of[col[i + (size_t)w * n]];
-                    if (last[b] != i) { obs[b].push_back(i); last[b] = i; }
-                }
-            std::vector<int> bptr(B + 1, 0), bstart(B), bdim(B), bobs, bidx;
-            bool ok = true;
-            for (int b = 0; b < B && ok; ++b) {
-                bstart[b] = c.cov.blocks[b].matstart; bdim[b] = c.cov.blocks[b].dim;
-                for (int i : obs[b]) {
-                    const size_t base = bidx.size();
-                    bidx.resize(base + DM, -1);
-                    for (int w = 0; w < width[i]; ++w) {
-                        const int q = col[i + (size_t)w * n];
-                        if (blk_of[q] != b) continue;
-                        int& slot = bidx[base + (q - bstart[b])];
-                        if (slot >= 0) { ok = false; break; }      // two entries of one observation on one effect: keep the CSR kernels
-                        slot = i + w * n;
-                    }
-                    bobs.push_back(i);
-                    if (!ok) break;
-                }
-                bptr[b + 1] = (int)bobs.size();
-            }
-            if (ok && !bobs.empty()) {
-                MCML_TRY(sp.blk_ptr.ensure(sizeof(int) * bptr.size())); MCML_TRY(sp.blk_start.ensure(sizeof(int) * B));
-                MCML_TRY(sp.blk_dim.ensure(sizeof(int) * B)); MCML_TRY(sp.blk_obs.ensure(sizeof(int) * bobs.size()));
-                MCML_TRY(sp.blk_idx.ensure(sizeof(int) * bidx.size()));
-                MCML_HIP(hipMemcpyAsync(sp.blk_ptr.p, bptr.data(), sizeof(int) * bptr.size(), hipMemcpyHostToDevice, c.stream));
-                MCML_HIP(hipMemcpyAsync(sp.blk_start.p, bstart.data(), sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
-                MCML_HIP(hipMemcpyAsync(sp.blk_dim.p, bdim.data(), sizeof(int) * B, hipMemcpyHostToDevice, c.stream));
-                MCML_HIP(hipMemcpyAsync(sp.blk_obs.p, bobs.data(), sizeof(int) * bobs.size(), hipMemcpyHostToDevice, c.stream));
-                MCML_HIP(hipMemcpyAsync(sp.blk_idx.p, bidx.data(), sizeof(int) * bidx.size(), hipMemcpyHostToDevice, c.stream));
-                MCML_HIP(hipStreamSynchronize(c.stream));
-                sp.nblk = B; sp.blk_dmax = DM;
-            }
-        }
-    }
     MCML_TRY(sp.row_start.ensure(sizeof(int) * (size_t)Q));
     MCML_HIP(hipMemcpyAsync(sp.row_start.p, start_of.data(), sizeof(int) * (size_t)Q, hipMemcpyHostToDevice, c.stream));
     MCML_HIP(hipStreamSynchronize(c.stream));

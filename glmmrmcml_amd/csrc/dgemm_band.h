@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
             typedef int i4s __attribute__((ext_vector_type(4)));
             i4s raw;
             const BandItem* ip = bp.items + it;
-            asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(raw) : "s"(ip) : "memory");
+            asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(raw) : "s"(ip) : "memory");
             item.band = raw.x; item.kt0 = raw.y; item.kt1 = raw.z; item.slot = raw.w;
         }
 #else

@@ -29,6 +29,35 @@ struct CmChain {                  // the per-chain scalars of hmc.hip::ChainArra
     long long* leap;
 };
 
+// ---- scalar loads of wave-uniform, read-only metadata --------------------------------------------------------------
+// hipcc keeps such loads on the vector pipe (64 lanes fetching one address) because it cannot prove that the kernel's
+// stores do not alias them; these issue them on the scalar pipe, a batch at a time with one wait.  The pointers must be
+// wave-uniform (SGPR operands); dword / dwordx2 loads need 4-byte alignment only.
+__device__ __forceinline__ void sload8(const int* ip, const double* dp, int (&iv)[8], double (&dv)[8])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_load_dword %0, %16, 0x0\n\ts_load_dword %1, %16, 0x4\n\ts_load_dword %2, %16, 0x8\n\ts_load_dword %3, %16, 0xc\n\t"
+                 "s_load_dword %4, %16, 0x10\n\ts_load_dword %5, %16, 0x14\n\ts_load_dword %6, %16, 0x18\n\ts_load_dword %7, %16, 0x1c\n\t"
+                 "s_load_dwordx2 %8, %17, 0x0\n\ts_load_dwordx2 %9, %17, 0x8\n\ts_load_dwordx2 %10, %17, 0x10\n\ts_load_dwordx2 %11, %17, 0x18\n\t"
+                 "s_load_dwordx2 %12, %17, 0x20\n\ts_load_dwordx2 %13, %17, 0x28\n\ts_load_dwordx2 %14, %17, 0x30\n\ts_load_dwordx2 %15, %17, 0x38\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(iv[0]), "=&s"(iv[1]), "=&s"(iv[2]), "=&s"(iv[3]), "=&s"(iv[4]), "=&s"(iv[5]), "=&s"(iv[6]), "=&s"(iv[7]),
+                   "=&s"(dv[0]), "=&s"(dv[1]), "=&s"(dv[2]), "=&s"(dv[3]), "=&s"(dv[4]), "=&s"(dv[5]), "=&s"(dv[6]), "=&s"(dv[7])
+                 : "s"(ip), "s"(dp) : "memory");
+#else
+    for (int u = 0; u < 8; ++u) { iv[u] = ip[u]; dv[u] = dp[u]; }
+#endif
+}
+__device__ __forceinline__ void sload_f64x2(const double* a, const double* b, double& x, double& y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(x), "=&s"(y) : "s"(a), "s"(b) : "memory");      // early clobber: an output must not reuse a pointer's registers
+#else
+    x = *a; y = *b;
+#endif
+}
+
 // ---- products -------------------------------------------------------------------------------------------------
 // forward: MU[c, i] = xb_i + sum_k val_k X[c, col_k] ; S = score(y_i, MU)      (ELL row of observation i)
 // a wave owns CM_FR consecutive observations: the k loop is outermost so that CM_FR independent gathers are in
@@ -40,22 +69,49 @@ __global__ __launch_bounds__(256) void k_cm_forward(int n, int C, int ldc, int W
                                                     double var_par, int store_mu, double* MU, double* S, int rpw)
 {
     (void)rpw;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.y * 64 + lane;
     const int i0 = (blockIdx.x * 4 + w) * CM_FR;
     if (c >= C || i0 >= n) return;
     double acc[CM_FR];
 #pragma unroll
     for (int r = 0; r < CM_FR; ++r) acc[r] = 0.0;
+    // the row metadata is wave-uniform and read-only: hand-written SCALAR loads (hipcc keeps them on the vector
+    // pipe because it cannot prove that the stores to MU / S do not alias them): CM_FR columns and values per
+    // batch, one wait
+    const bool full = i0 + CM_FR <= n;
     for (int k = 0; k < W; ++k) {
-        double xv[CM_FR], vv[CM_FR];
+        int qv[CM_FR]; double vv[CM_FR];
+        if (full) {
+            const int* cp_ = col + i0 + (size_t)k * n;
+            const double* vp_ = val + i0 + (size_t)k * n;
+#if defined(__HIP_DEVICE_COMPILE__)
+            static_assert(CM_FR == 4, "scalar batch below");
+            typedef int i4s_ __attribute__((ext_vector_type(4)));
+            typedef double d2s_ __attribute__((ext_vector_type(2)));
+            if ((((size_t)cp_) & 15) == 0 && (((size_t)vp_) & 15) == 0) {
+                i4s_ cq; d2s_ v01, v23;
+                asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %4, 0x0\n\ts_load_dwordx4 %2, %4, 0x10\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&s"(cq), "=&s"(v01), "=&s"(v23) : "s"(cp_), "s"(vp_) : "memory");
+                qv[0] = cq.x; qv[1] = cq.y; qv[2] = cq.z; qv[3] = cq.w;
+                vv[0] = v01.x; vv[1] = v01.y; vv[2] = v23.x; vv[3] = v23.y;
+            } else
+#endif
+            {
 #pragma unroll
-        for (int r = 0; r < CM_FR; ++r) {
-            const int i = (i0 + r < n) ? i0 + r : n - 1;
-            const int q = __builtin_amdgcn_readfirstlane(col[i + (size_t)k * n]);
-            vv[r] = val[i + (size_t)k * n];                            // uniform address: one value for the wave
-            xv[r] = X[c + (size_t)q * ldc];
+                for (int r = 0; r < CM_FR; ++r) { qv[r] = __builtin_amdgcn_readfirstlane(cp_[r]); vv[r] = vp_[r]; }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < CM_FR; ++r) {
+                const int i = (i0 + r < n) ? i0 + r : n - 1;
+                qv[r] = __builtin_amdgcn_readfirstlane(col[i + (size_t)k * n]);
+                vv[r] = val[i + (size_t)k * n];
+            }
         }
+        double xv[CM_FR];
+#pragma unroll
+        for (int r = 0; r < CM_FR; ++r) xv[r] = X[c + (size_t)qv[r] * ldc];
 #pragma unroll
         for (int r = 0; r < CM_FR; ++r) acc[r] += vv[r] * xv[r];
     }
@@ -63,10 +119,12 @@ __global__ __launch_bounds__(256) void k_cm_forward(int n, int C, int ldc, int W
     for (int r = 0; r < CM_FR; ++r) {
         const int i = i0 + r;
         if (i < n) {
-            const double mu = xb[i] + acc[r];
+            double xbi, yi;
+            sload_f64x2(xb + i, y + i, xbi, yi);
+            const double mu = xbi + acc[r];
             const size_t off = c + (size_t)i * ldc;
             if (store_mu) MU[off] = mu;
-            S[off] = BETA ? glm_score_beta(y[i], mu, var_par) : glm_score(y[i], mu, flink);
+            S[off] = BETA ? glm_score_beta(yi, mu, var_par) : glm_score(yi, mu, flink);
         }
     }
 }
@@ -119,7 +177,7 @@ __global__ __launch_bounds__(256) void k_cm_backward_long(int Q, int C, int ldc,
                                                           double post, int mode)
 {
     __shared__ double sh[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = blockIdx.x;
     const int c = blockIdx.y * 64 + lane;
     const bool cin = c < C;
@@ -130,11 +188,12 @@ __global__ __launch_bounds__(256) void k_cm_backward_long(int Q, int C, int ldc,
     double acc = 0.0;
     int t = a;
     for (; t + 8 <= b; t += 8) {
-        double sv[8];
+        int iv[8]; double vv[8], sv[8];
+        sload8(ci + t, val + t, iv, vv);                               // indices and values on the scalar pipe
 #pragma unroll
-        for (int u = 0; u < 8; ++u) sv[u] = S[cc + (size_t)__builtin_amdgcn_readfirstlane(ci[t + u]) * ldc];
+        for (int u = 0; u < 8; ++u) sv[u] = S[cc + (size_t)iv[u] * ldc];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += val[t + u] * sv[u];
+        for (int u = 0; u < 8; ++u) acc += vv[u] * sv[u];
     }
     for (; t < b; ++t) acc += val[t] * S[cc + (size_t)__builtin_amdgcn_readfirstlane(ci[t]) * ldc];
     sh[w][lane] = acc;

@@ -25,6 +25,7 @@ struct HmcState {
     int partial_slots = 0;
     bool cm = false;            // chain-major state (sparse ZL operator, hmc_cm.h): element (c, r) at c + r * ld
     DevBuf cm_part, cm_acc;     // chain-major path: partial sums (ll | lp | kin | ss), accept flags
+    DevMat LX, ZS;              // factored operator (SparseZL::factored): L X and Z' S, C x Q
 };
 
 // ZL = Z L held as padded-CSR (ELL) rows plus its transpose in CSR: used by the sampler (chain-major state, hmc_cm.h)
@@ -38,6 +39,12 @@ struct SparseZL {
     DevBuf ell_col, ell_src, ell_z, ell_val;   // n x W (column-major): column of ZL, flat index into L, Z value, value
     DevBuf csr_ptr, csr_i, csr_pos, csr_val;   // rows of ZL' : q -> (observation, position in ell_val, value)
     DevBuf row_start;                          // first column of row q of the block-diagonal L (U = L V, hmc.hip)
+    // factored form ZL = Z * L (hmc_cm.h): chosen when a row of ZL mostly repeats a row of L, i.e. when gathering
+    // through Z and applying the blocks of L separately touches far fewer entries than nnz(ZL)
+    bool factored = false;
+    long nnz_z = 0, nnz_l = 0;
+    DevBuf zcsr_ptr, zcsr_i, zcsr_val;         // rows of Z' : q -> (observation, value)
+    DevBuf row_end;                            // one past the last row of column q of L (= end of q's block)
 };
 
 // HIP-event timing of the dominant kernels, on the stream they are launched on

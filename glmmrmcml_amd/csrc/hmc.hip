@@ -418,9 +418,10 @@ static int hmc_alloc(Ctx& c, int C)
         MCML_TRY(h.GRAD.alloc(C, c.Q)); MCML_TRY(h.GRADP.alloc(C, c.Q));
         MCML_TRY(h.MU.alloc(C, c.n)); MCML_TRY(h.S.alloc(C, c.n));
         MCML_TRY(h.chain.ensure(sizeof(double) * (size_t)round_up(C, 16) * 8));
-        const size_t nchn = (size_t)(c.n + CM_ROWS - 1) / CM_ROWS, nchq = (size_t)(c.Q + CM_ROWS - 1) / CM_ROWS;
+        const size_t nchn = (size_t)(c.n + CM_ROWS - 1) / CM_ROWS, nchq = (size_t)(c.Q + cm_qrows(c.Q) - 1) / cm_qrows(c.Q);
         MCML_TRY(h.cm_part.ensure(sizeof(double) * (nchn + 3 * nchq + 4) * (size_t)h.V.ld));
         MCML_TRY(h.cm_acc.ensure(sizeof(int) * (size_t)round_up(C, 64)));
+        if (c.sp.factored) { MCML_TRY(h.LX.alloc(C, c.Q)); MCML_TRY(h.ZS.alloc(C, c.Q)); }
         return MCML_OK;
     }
     MCML_TRY(h.V.alloc(c.Q, C)); MCML_TRY(h.R.alloc(c.Q, C)); MCML_TRY(h.UP.alloc(c.Q, C));
@@ -462,12 +463,19 @@ static int hmc_forward(Ctx& c, const double* X, int ldx, double var_par, bool st
     if (h.cm) {
         const int rpw = CM_FR;
         dim3 grid((c.n + 4 * rpw - 1) / (4 * rpw), (h.C + 63) / 64);
+        // factored operator: LX = L X first, then the rows of Z gather from LX
+        int W = c.sp.W; const int* col = c.sp.ell_col.as<int>(); const double* val = c.sp.ell_val.d(); const double* Xin = X;
+        if (c.sp.factored) {
+            hipLaunchKernelGGL(k_cm_Lrow, dim3((c.Q + 3) / 4, (h.C + 63) / 64), dim3(256), 0, c.stream, c.Q, h.C, h.V.ld,
+                               c.sp.row_start.as<int>(), c.L.d(), c.L.ld, X, h.LX.d());
+            W = c.z_width; col = c.z_idx.as<int>(); val = c.z_val.d(); Xin = h.LX.d();
+        }
         if (c.flink == 12)
-            hipLaunchKernelGGL((k_cm_forward<true>), grid, dim3(256), 0, c.stream, c.n, h.C, h.V.ld, c.sp.W, c.sp.ell_col.as<int>(),
-                               c.sp.ell_val.d(), X, c.xb.d(), c.y.d(), c.flink, var_par, store_mu ? 1 : 0, h.MU.d(), h.S.d(), rpw);
+            hipLaunchKernelGGL((k_cm_forward<true>), grid, dim3(256), 0, c.stream, c.n, h.C, h.V.ld, W, col, val, Xin, c.xb.d(),
+                               c.y.d(), c.flink, var_par, store_mu ? 1 : 0, h.MU.d(), h.S.d(), rpw);
         else
-            hipLaunchKernelGGL((k_cm_forward<false>), grid, dim3(256), 0, c.stream, c.n, h.C, h.V.ld, c.sp.W, c.sp.ell_col.as<int>(),
-                               c.sp.ell_val.d(), X, c.xb.d(), c.y.d(), c.flink, var_par, store_mu ? 1 : 0, h.MU.d(), h.S.d(), rpw);
+            hipLaunchKernelGGL((k_cm_forward<false>), grid, dim3(256), 0, c.stream, c.n, h.C, h.V.ld, W, col, val, Xin, c.xb.d(),
+                               c.y.d(), c.flink, var_par, store_mu ? 1 : 0, h.MU.d(), h.S.d(), rpw);
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
     } else if (c.flink == 12)      // beta/logit: the digamma score is its own instantiation (glm.h)
         rc = hmc_forward_launch(c, X, ldx, EpiForwardT<true>{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink,
@@ -487,17 +495,28 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
     const int slot = c.prof.begin(c.stream, 1, chain);
     int rc;
     if (h.cm) {
-        if (c.sp.nnz >= 24L * c.Q) {          // long rows: a workgroup per (random effect, 64 chains)
-            hipLaunchKernelGGL(k_cm_backward_long, dim3(c.Q, (h.C + 63) / 64), dim3(256), 0, c.stream, c.Q, h.C, h.V.ld,
-                               c.sp.csr_ptr.as<int>(), c.sp.csr_i.as<int>(), c.sp.csr_val.d(), h.S.d(), Xs, G, h.R.d(), h.UP.d(),
-                               ca.e, ca.steps, s, glm_score_post(var_par, c.flink), mode);
+        // factored operator: T = Z' S (mode 2: the raw sums), then g = -x + post * L' T with the leapfrog update
+        const bool f = c.sp.factored;
+        const int* ptr = f ? c.sp.zcsr_ptr.as<int>() : c.sp.csr_ptr.as<int>();
+        const int* ci = f ? c.sp.zcsr_i.as<int>() : c.sp.csr_i.as<int>();
+        const double* cv = f ? c.sp.zcsr_val.d() : c.sp.csr_val.d();
+        double* out = f ? h.ZS.d() : G;
+        const int m1 = f ? 2 : mode;
+        const double post = glm_score_post(var_par, c.flink);
+        if ((f ? c.sp.nnz_z : c.sp.nnz) >= 24L * c.Q) {          // long rows: a workgroup per (random effect, 64 chains)
+            const int ncb = (h.C + 63) / 64;
+            hipLaunchKernelGGL(k_cm_backward_long, dim3((c.Q * ncb + 7) / 8 * 8), dim3(256), 0, c.stream, c.Q, h.C, h.V.ld,
+                               ptr, ci, cv, h.S.d(), Xs, out, h.R.d(), h.UP.d(), ca.e, ca.steps, s, post, m1, ncb);
         } else {
             const int rpw = 2;
             dim3 grid((c.Q + 4 * rpw - 1) / (4 * rpw), (h.C + 63) / 64);
-            hipLaunchKernelGGL(k_cm_backward, grid, dim3(256), 0, c.stream, c.Q, h.C, h.V.ld, c.sp.csr_ptr.as<int>(),
-                               c.sp.csr_i.as<int>(), c.sp.csr_val.d(), h.S.d(), Xs, G, h.R.d(), h.UP.d(), ca.e, ca.steps, s,
-                               glm_score_post(var_par, c.flink), mode, rpw);
+            hipLaunchKernelGGL(k_cm_backward, grid, dim3(256), 0, c.stream, c.Q, h.C, h.V.ld, ptr, ci, cv, h.S.d(), Xs, out,
+                               h.R.d(), h.UP.d(), ca.e, ca.steps, s, post, m1, rpw);
         }
+        if (f)
+            hipLaunchKernelGGL(k_cm_Lcol, dim3((c.Q + 3) / 4, (h.C + 63) / 64), dim3(256), 0, c.stream, c.Q, h.C, h.V.ld,
+                               c.sp.row_end.as<int>(), c.L.d(), c.L.ld, h.ZS.d(), Xs, G, h.R.d(), h.UP.d(), ca.e, ca.steps, s,
+                               post, mode);
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
         c.prof.end(c.stream, slot);
         return rc;
@@ -522,7 +541,7 @@ static CmParts cm_parts(const Ctx& c)
 {
     const HmcState& h = c.hmc;
     CmParts p;
-    p.nchn = (c.n + CM_ROWS - 1) / CM_ROWS; p.nchq = (c.Q + CM_ROWS - 1) / CM_ROWS; p.ldp = h.V.ld;
+    p.nchn = (c.n + CM_ROWS - 1) / CM_ROWS; p.nchq = (c.Q + cm_qrows(c.Q) - 1) / cm_qrows(c.Q); p.ldp = h.V.ld;
     p.ll = h.cm_part.d(); p.lp = p.ll + (size_t)p.nchn * p.ldp; p.kin = p.lp + (size_t)p.nchq * p.ldp;
     p.ss = p.kin + (size_t)p.nchq * p.ldp;
     return p;
@@ -532,8 +551,16 @@ static int cm_logprob_partials(Ctx& c, const double* X, const double* R, double 
 {
     HmcState& h = c.hmc;
     const CmParts p = cm_parts(c);
-    hipLaunchKernelGGL(k_cm_logprob_partials, dim3((h.C + 63) / 64, p.nchn + p.nchq), dim3(256), 0, c.stream, h.MU.d(), X, R,
-                       h.V.ld, c.n, c.Q, h.C, c.y.d(), var_par, c.flink, p.nchn, p.ll, p.lp, p.kin, p.ldp);
+    const dim3 grid((h.C + 63) / 64, p.nchn + p.nchq);
+#define MCML_LP_LAUNCH(FL) hipLaunchKernelGGL((k_cm_logprob_partials<FL>), grid, dim3(256), 0, c.stream, h.MU.d(), X, R, h.V.ld, \
+                       c.n, c.Q, h.C, c.y.d(), var_par, c.flink, p.nchn, p.ll, p.lp, p.kin, p.ldp)
+    switch (c.flink) {                       // the common families get their own instantiation
+    case 1: MCML_LP_LAUNCH(1); break;        // poisson / log
+    case 3: MCML_LP_LAUNCH(3); break;        // binomial / logit
+    case 7: MCML_LP_LAUNCH(7); break;        // gaussian / identity
+    default: MCML_LP_LAUNCH(0); break;
+    }
+#undef MCML_LP_LAUNCH
     MCML_HIP(hipGetLastError());
     return MCML_OK;
 }
@@ -547,7 +574,7 @@ static int hmc_eval_state(Ctx& c, double var_par)
     if (h.cm) {
         const CmParts p = cm_parts(c);
         MCML_TRY(cm_logprob_partials(c, h.V.d(), nullptr, var_par));
-        hipLaunchKernelGGL(k_cm_lp0_fin, dim3((h.C + 255) / 256), dim3(256), 0, c.stream, p.ll, p.lp, p.nchn, p.nchq, p.ldp,
+        hipLaunchKernelGGL(k_cm_lp0_fin, dim3((h.C + 63) / 64), dim3(256), 0, c.stream, p.ll, p.lp, p.nchn, p.nchq, p.ldp,
                            h.C, ca.lpcur);
     } else
     hipLaunchKernelGGL(k_hmc_lp0, dim3(h.C), dim3(256), 0, c.stream, h.MU.d(), h.MU.ld, c.n, h.V.d(), h.V.ld, c.Q,
@@ -592,7 +619,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
     if (flags_out) MCML_TRY(d_flags.ensure((size_t)C * total));
     if (probs_out) MCML_TRY(d_probs.ensure(sizeof(double) * (size_t)C * total));
 
-    const int nchq = (Q + CM_ROWS - 1) / CM_ROWS;
+    const int nchq = (Q + cm_qrows(Q) - 1) / cm_qrows(Q);
     auto store = [&](int stride, int col) {
         if (h.cm)      // SAMP[k + (c * stride + col) * lds] = V[c + k * ldc]
             hipLaunchKernelGGL(k_cm_transpose, dim3((Q + 31) / 32, (C + 31) / 32), dim3(256), 0, c.stream, h.V.d(), h.V.ld, Q, C,
@@ -636,7 +663,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
             hipLaunchKernelGGL(k_cm_propose, dim3((C + 63) / 64, p.nchq), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(),
                                h.UP.d(), h.V.ld, Q, C, cm_chain(ca), seed, (uint32_t)o->chain_offset, iter_idx, it, p_mom,
                                p.ss, p.ldp);
-            hipLaunchKernelGGL(k_cm_propose_fin, dim3((C + 255) / 256), dim3(256), 0, c.stream, p.ss, p.nchq, p.ldp, C,
+            hipLaunchKernelGGL(k_cm_propose_fin, dim3((C + 63) / 64), dim3(256), 0, c.stream, p.ss, p.nchq, p.ldp, C,
                                cm_chain(ca), o->lambda, o->max_steps);
         } else
         hipLaunchKernelGGL(k_hmc_propose, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(), h.UP.d(),
@@ -670,7 +697,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         if (h.cm) {
             const CmParts p = cm_parts(c);
             MCML_TRY(cm_logprob_partials(c, h.UP.d(), h.R.d(), var_par));
-            hipLaunchKernelGGL(k_cm_accept_fin, dim3((C + 255) / 256), dim3(256), 0, c.stream, p.ll, p.lp, p.kin, p.nchn, p.nchq,
+            hipLaunchKernelGGL(k_cm_accept_fin, dim3((C + 63) / 64), dim3(256), 0, c.stream, p.ll, p.lp, p.kin, p.nchn, p.nchq,
                                p.ldp, C, cm_chain(ca), o->target_accept, adapt, it,
                                flags_out ? d_flags.as<uint8_t>() : nullptr, probs_out ? d_probs.d() : nullptr,
                                h.cm_acc.as<int>());

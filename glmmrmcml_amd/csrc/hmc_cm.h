@@ -129,6 +129,26 @@ __global__ __launch_bounds__(256) void k_cm_forward(int n, int C, int ldc, int W
     }
 }
 
+// the update that follows the backward product (hmc.hip::EpiBackward): acc = (ZL' S)[c, q]
+//   mode 0: G = -x + post * acc ; mode 1: the same inside a leapfrog trajectory of st steps (step s) with the momentum and
+//   position updates ; mode 2: G = acc (the first factor of the factored operator, below)
+__device__ __forceinline__ void cm_leapfrog(double acc, size_t off, const double* Xs, double* G, double* R, double* UP,
+                                            double en, int st, int s, double post, int mode)
+{
+    if (mode == 2) { G[off] = acc; return; }
+    if (mode == 1 && s >= st) return;
+    const double x = Xs[off];
+    double g = -1.0 * x;
+    g = g + post * acc;
+    if (mode != 1 || s + 1 >= st) G[off] = g;                          // mid-trajectory gradients are never read
+    if (mode == 1) {
+        double rr = R[off];
+        rr = rr + (en / 2) * g;
+        if (s + 1 < st) { rr = rr + (en / 2) * g; UP[off] = x + en * rr; }
+        R[off] = rr;
+    }
+}
+
 // backward: g = -x + post * sum_t val_t S[c, i_t]  (CSR row q of ZL'), then the leapfrog update of hmc.hip::EpiBackward
 __global__ __launch_bounds__(256) void k_cm_backward(int Q, int C, int ldc, const int* ptr, const int* ci,
                                                      const double* val, const double* S, const double* Xs, double* G,
@@ -153,18 +173,7 @@ __global__ __launch_bounds__(256) void k_cm_backward(int Q, int C, int ldc, cons
             acc += val[t] * s0; acc += val[t + 1] * s1; acc += val[t + 2] * s2; acc += val[t + 3] * s3;
         }
         for (; t < t1; ++t) acc += val[t] * S[c + (size_t)__builtin_amdgcn_readfirstlane(ci[t]) * ldc];
-        if (mode == 1 && s >= st) continue;
-        const size_t off = c + (size_t)q * ldc;
-        const double x = Xs[off];
-        double g = -1.0 * x;
-        g = g + post * acc;
-        if (mode != 1 || s + 1 >= st) G[off] = g;                      // mid-trajectory gradients are never read
-        if (mode == 1) {
-            double rr = R[off];
-            rr = rr + (en / 2) * g;
-            if (s + 1 < st) { rr = rr + (en / 2) * g; UP[off] = x + en * rr; }
-            R[off] = rr;
-        }
+        cm_leapfrog(acc, c + (size_t)q * ldc, Xs, G, R, UP, en, st, s, post, mode);
     }
 }
 
@@ -174,12 +183,18 @@ __global__ __launch_bounds__(256) void k_cm_backward(int Q, int C, int ldc, cons
 __global__ __launch_bounds__(256) void k_cm_backward_long(int Q, int C, int ldc, const int* ptr, const int* ci,
                                                           const double* val, const double* S, const double* Xs, double* G,
                                                           double* R, double* UP, const double* e, const int* steps, int s,
-                                                          double post, int mode)
+                                                          double post, int mode, int ncb)
 {
     __shared__ double sh[4][64];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q = blockIdx.x;
-    const int c = blockIdx.y * 64 + lane;
+    // workgroup id -> (effect, chain block): ids go round-robin over the 8 XCDs, so XCD x takes the CONTIGUOUS range
+    // [x, x + 1) * per8 of the (chain block, effect) order -- the effects of one covariance block gather the same rows
+    // of S and now do so through one L2
+    const int T = Q * ncb, per8 = (T + 7) >> 3;
+    const int vid = (int)(blockIdx.x & 7) * per8 + (int)(blockIdx.x >> 3);
+    if (vid >= T) return;
+    const int q = vid % Q;
+    const int c = (vid / Q) * 64 + lane;
     const bool cin = c < C;
     const int cc = cin ? c : 0;
     const int t0 = __builtin_amdgcn_readfirstlane(ptr[q]), t1 = __builtin_amdgcn_readfirstlane(ptr[q + 1]);
@@ -201,23 +216,77 @@ __global__ __launch_bounds__(256) void k_cm_backward_long(int Q, int C, int ldc,
     if (w != 0 || !cin) return;
     acc = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
     int st = 0; double en = 0.0;
-    if (mode == 1) { st = steps[c]; en = e[c]; if (s >= st) return; }
-    const size_t off = c + (size_t)q * ldc;
-    const double x = Xs[off];
-    double g = -1.0 * x;
-    g = g + post * acc;
-    if (mode != 1 || s + 1 >= st) G[off] = g;
-    if (mode == 1) {
-        double rr = R[off];
-        rr = rr + (en / 2) * g;
-        if (s + 1 < st) { rr = rr + (en / 2) * g; UP[off] = x + en * rr; }
-        R[off] = rr;
-    }
+    if (mode == 1) { st = steps[c]; en = e[c]; }
+    cm_leapfrog(acc, c + (size_t)q * ldc, Xs, G, R, UP, en, st, s, post, mode);
 }
 
 // (A block-at-a-time variant -- one workgroup per covariance block, S read once, the block's effects in DMAX
 // accumulators with wave-uniform values -- measured 121 us against 72 us for the kernel above at config 4: the
 // scalar index loads per observation cost more than the re-reads of S from L2 save.)
+
+// ---- factored operator ZL = Z * L ------------------------------------------------------------------------------------
+// When the covariance blocks are not tiny a row of ZL repeats a row of L for every observation of that random effect
+// (config 4: 16000 x 8.5 entries for 320 x 8.5 distinct values).  The sampler then applies the two factors in turn:
+//   forward   LX = L X        (k_cm_Lrow, Q x C, tiny)      MU = xb + Z LX    (k_cm_forward on the rows of Z)
+//   backward  T  = Z' S       (k_cm_backward*, mode 2)      g  = -x + post * L' T, leapfrog update (k_cm_Lcol)
+// so that X / S are gathered nnz(Z) times instead of nnz(ZL) times.
+__device__ __forceinline__ double sload_f64(const double* a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double x;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(x) : "s"(a) : "memory");
+    return x;
+#else
+    return *a;
+#endif
+}
+
+// LX[c, q] = sum_{j = start(q)}^{q} L[q, j] X[c, j]  (row q of the block-diagonal lower-triangular L, ascending j)
+__global__ __launch_bounds__(256) void k_cm_Lrow(int Q, int C, int ldc, const int* start, const double* L, int ldl,
+                                                 const double* X, double* LX)
+{
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = blockIdx.x * 4 + w;
+    const int c = blockIdx.y * 64 + lane;
+    if (q >= Q || c >= C) return;
+    const int s0 = __builtin_amdgcn_readfirstlane(start[q]);
+    double acc = 0.0;
+    int j = s0;
+    for (; j + 4 <= q + 1; j += 4) {
+        const double l0 = sload_f64(L + q + (size_t)j * ldl), l1 = sload_f64(L + q + (size_t)(j + 1) * ldl);
+        const double l2 = sload_f64(L + q + (size_t)(j + 2) * ldl), l3 = sload_f64(L + q + (size_t)(j + 3) * ldl);
+        const double x0 = X[c + (size_t)j * ldc], x1 = X[c + (size_t)(j + 1) * ldc];
+        const double x2 = X[c + (size_t)(j + 2) * ldc], x3 = X[c + (size_t)(j + 3) * ldc];
+        acc += l0 * x0; acc += l1 * x1; acc += l2 * x2; acc += l3 * x3;
+    }
+    for (; j <= q; ++j) acc += sload_f64(L + q + (size_t)j * ldl) * X[c + (size_t)j * ldc];
+    LX[c + (size_t)q * ldc] = acc;
+}
+
+// acc = sum_{j = q}^{end(q) - 1} L[j, q] T[c, j]  (column q of L, ascending j), then the update of cm_leapfrog
+__global__ __launch_bounds__(256) void k_cm_Lcol(int Q, int C, int ldc, const int* end, const double* L, int ldl,
+                                                 const double* T, const double* Xs, double* G, double* R, double* UP,
+                                                 const double* e, const int* steps, int s, double post, int mode)
+{
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = blockIdx.x * 4 + w;
+    const int c = blockIdx.y * 64 + lane;
+    if (q >= Q || c >= C) return;
+    const int j1 = __builtin_amdgcn_readfirstlane(end[q]);
+    const double* Lq = L + (size_t)q * ldl;
+    double acc = 0.0;
+    int j = q;
+    for (; j + 4 <= j1; j += 4) {
+        const double l0 = sload_f64(Lq + j), l1 = sload_f64(Lq + j + 1), l2 = sload_f64(Lq + j + 2), l3 = sload_f64(Lq + j + 3);
+        const double t0 = T[c + (size_t)j * ldc], t1 = T[c + (size_t)(j + 1) * ldc];
+        const double t2 = T[c + (size_t)(j + 2) * ldc], t3 = T[c + (size_t)(j + 3) * ldc];
+        acc += l0 * t0; acc += l1 * t1; acc += l2 * t2; acc += l3 * t3;
+    }
+    for (; j < j1; ++j) acc += sload_f64(Lq + j) * T[c + (size_t)j * ldc];
+    int st = 0; double en = 0.0;
+    if (mode == 1) { st = steps[c]; en = e[c]; }
+    cm_leapfrog(acc, c + (size_t)q * ldc, Xs, G, R, UP, en, st, s, post, mode);
+}
 
 // ---- per-chain kernels -------------------------------------------------------------------------------------------
 // grid (chains / 64, row chunks of CM_ROWS); wave w of a workgroup takes rows w, w + 4, ... of the chunk and the four
@@ -232,6 +301,34 @@ __device__ __forceinline__ void cm_block_partial(double v, double* part, int chu
     __syncthreads();
 }
 
+// sum over the chunks of one partial array, for the 64 chains of a 256-thread workgroup: wave w adds its contiguous
+// quarter of the chunks in order (eight loads in flight), the quarters are added in wave order through LDS.  One
+// thread per chain walking all chunks was a chain of nchunk dependent loads (63 us at config 4).
+__device__ __forceinline__ double cm_sum_chunks(const double* part, int nchunk, int ldp, int cc)
+{
+    __shared__ double sh[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int per = (nchunk + 3) >> 2, k0 = w * per, k1 = (k0 + per < nchunk) ? k0 + per : nchunk;
+    double a = 0.0;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + u) * ldp + cc];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; k < k1; ++k) a += part[(size_t)k * ldp + cc];
+    __syncthreads();
+    sh[w][lane] = a;
+    __syncthreads();
+    return ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+}
+
+// rows of the random-effect-sized arrays per workgroup of the per-chain kernels: small chunks when Q is small, so
+// that config 4's 320 effects still spread over the chip
+__host__ __device__ inline int cm_qrows(int Q) { return Q <= 4096 ? 16 : CM_ROWS; }
+
 __global__ __launch_bounds__(256) void k_cm_init(double* V, int ldc, int Q, int C, CmChain ca, uint64_t seed,
                                                  uint32_t chain_offset, uint32_t iter_idx, const double* inj_init)
 {
@@ -239,8 +336,8 @@ __global__ __launch_bounds__(256) void k_cm_init(double* V, int ldc, int Q, int 
     const int c = blockIdx.x * 64 + lane;
     if (c >= C) return;
     const uint32_t gid = chain_offset + (uint32_t)c;
-    const int q0 = blockIdx.y * CM_ROWS;
-    for (int q = q0 + w; q < q0 + CM_ROWS && q < Q; q += 4)
+    const int QR = cm_qrows(Q), q0 = blockIdx.y * QR;
+    for (int q = q0 + w; q < q0 + QR && q < Q; q += 4)
         V[c + (size_t)q * ldc] = inj_init ? inj_init[q + (size_t)c * Q]
                                           : rng_normal(seed, (uint32_t)q, gid, 0u, 16u * iter_idx + 0u);
     if (blockIdx.y == 0 && w == 0) {                              // initialise_u, mhmcmc.h:47-59
@@ -252,6 +349,9 @@ __global__ __launch_bounds__(256) void k_cm_init(double* V, int ldc, int Q, int 
 
 // partial sums of log f(y_i | MU[c,i]) over observation chunks [0, nchunk_n) and of log N(X[c,q]; 0, 1) (+ R[c,q]^2
 // when R is given) over random-effect chunks: part_ll / part_lp / part_kin, ld = ldp
+// FL != 0: the family / link is a compile-time constant (the 12-way switch of glm_logpdf with its lgamma / tgamma / erfc
+// bodies inlined cost 290 VGPRs, one wave per SIMD: 109 us at config 4)
+template <int FL>
 __global__ __launch_bounds__(256) void k_cm_logprob_partials(const double* MU, const double* X, const double* R, int ldc,
                                                              int n, int Q, int C, const double* y, double var_par,
                                                              int flink, int nchunk_n, double* part_ll, double* part_lp,
@@ -262,14 +362,25 @@ __global__ __launch_bounds__(256) void k_cm_logprob_partials(const double* MU, c
     const bool cin = c < C;
     const int cc = cin ? c : 0;
     if ((int)blockIdx.y < nchunk_n) {
-        const int i0 = blockIdx.y * CM_ROWS;
+        const int fl = FL ? FL : flink;
+        const int i0 = blockIdx.y * CM_ROWS, i1 = (i0 + CM_ROWS < n) ? i0 + CM_ROWS : n;
         double ll = 0.0;
-        for (int i = i0 + w; i < i0 + CM_ROWS && i < n; i += 4) ll += glm_logpdf(y[i], MU[cc + (size_t)i * ldc], var_par, flink);
+        for (int i = i0 + w; i < i1; i += 16) {                       // rows i, i + 4, i + 8, i + 12: four loads in flight
+            double m[4], yy[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = (i + 4 * u < i1) ? i + 4 * u : i1 - 1;
+                m[u] = MU[cc + (size_t)r * ldc]; yy[u] = y[r];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i + 4 * u < i1) ll += glm_logpdf(yy[u], m[u], var_par, fl);
+        }
         cm_block_partial(ll, part_ll, blockIdx.y, ldp, c, cin);
     } else {
-        const int ch = blockIdx.y - nchunk_n, q0 = ch * CM_ROWS;
+        const int QR = cm_qrows(Q);
+        const int ch = blockIdx.y - nchunk_n, q0 = ch * QR;
         double lp = 0.0, kin = 0.0;
-        for (int q = q0 + w; q < q0 + CM_ROWS && q < Q; q += 4) {
+        for (int q = q0 + w; q < q0 + QR && q < Q; q += 4) {
             lp += glm_logpdf(X[cc + (size_t)q * ldc], 0, 1, 7);
             if (R) { const double r = R[cc + (size_t)q * ldc]; kin += r * r; }
         }
@@ -278,14 +389,15 @@ __global__ __launch_bounds__(256) void k_cm_logprob_partials(const double* MU, c
     }
 }
 
+// the three kernels below: one 256-thread workgroup per 64 chains (cm_sum_chunks), wave 0 finishes
 __global__ __launch_bounds__(256) void k_cm_lp0_fin(const double* part_ll, const double* part_lp, int nchunk_n,
                                                     int nchunk_q, int ldp, int C, double* lpcur)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < nchunk_n; ++k) a += part_ll[(size_t)k * ldp + c];
-    for (int k = 0; k < nchunk_q; ++k) b += part_lp[(size_t)k * ldp + c];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int cc = c < C ? c : 0;
+    const double a = cm_sum_chunks(part_ll, nchunk_n, ldp, cc);
+    const double b = cm_sum_chunks(part_lp, nchunk_q, ldp, cc);
+    if (threadIdx.x >= 64 || c >= C) return;
     lpcur[c] = a + b;                                             // ll.sum() + lp.sum(), mcmlmodel.h:151
 }
 
@@ -301,10 +413,10 @@ __global__ __launch_bounds__(256) void k_cm_propose(const double* V, const doubl
     const int cc = cin ? c : 0;
     const uint32_t gid = chain_offset + (uint32_t)cc;
     const double e = ca.e[cc];
-    const int q0 = blockIdx.y * CM_ROWS;
+    const int QR = cm_qrows(Q), q0 = blockIdx.y * QR;
     double ss = 0.0;
     if (cin)
-        for (int q = q0 + w; q < q0 + CM_ROWS && q < Q; q += 4) {
+        for (int q = q0 + w; q < q0 + QR && q < Q; q += 4) {
             const size_t off = c + (size_t)q * ldc;
             double r = inj_mom ? inj_mom[q + ((size_t)it * C + c) * Q]
                                : rng_normal(seed, (uint32_t)q, gid, (uint32_t)it, 16u * iter_idx + 2u);
@@ -320,10 +432,9 @@ __global__ __launch_bounds__(256) void k_cm_propose(const double* V, const doubl
 __global__ __launch_bounds__(256) void k_cm_propose_fin(const double* part_ss, int nchunk_q, int ldp, int C, CmChain ca,
                                                         double lambda, int max_steps)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double tot = 0.0;
-    for (int k = 0; k < nchunk_q; ++k) tot += part_ss[(size_t)k * ldp + c];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const double tot = cm_sum_chunks(part_ss, nchunk_q, ldp, c < C ? c : 0);
+    if (threadIdx.x >= 64 || c >= C) return;
     ca.K0[c] = 0.5 * tot;
     double st = round(lambda / ca.e[c]);                          // mhmcmc.h:69-70
     if (!(st >= 1.0)) st = 1.0;
@@ -338,11 +449,12 @@ __global__ __launch_bounds__(256) void k_cm_accept_fin(const double* part_ll, co
                                                        double target_accept, int adapt, int it, uint8_t* flags,
                                                        double* probs, int* accflag)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0, kin = 0.0;
-    for (int k = 0; k < nchunk_n; ++k) a += part_ll[(size_t)k * ldp + c];
-    for (int k = 0; k < nchunk_q; ++k) { b += part_lp[(size_t)k * ldp + c]; kin += part_kin[(size_t)k * ldp + c]; }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int cc = c < C ? c : 0;
+    const double a = cm_sum_chunks(part_ll, nchunk_n, ldp, cc);
+    const double b = cm_sum_chunks(part_lp, nchunk_q, ldp, cc);
+    const double kin = cm_sum_chunks(part_kin, nchunk_q, ldp, cc);
+    if (threadIdx.x >= 64 || c >= C) return;
     const double l2 = a + b;
     const double lprt = 0.5 * kin, lpr = ca.K0[c], l1 = ca.lpcur[c];
     const double prob = fmin(1.0, exp(-l1 + lpr + l2 - lprt));
@@ -376,8 +488,8 @@ __global__ __launch_bounds__(256) void k_cm_commit(double* V, double* GRAD, cons
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     if (c >= C || !accflag[c]) return;
-    const int q0 = blockIdx.y * CM_ROWS;
-    for (int q = q0 + w; q < q0 + CM_ROWS && q < Q; q += 4) {
+    const int QR = cm_qrows(Q), q0 = blockIdx.y * QR;
+    for (int q = q0 + w; q < q0 + QR && q < Q; q += 4) {
         const size_t off = c + (size_t)q * ldc;
         V[off] = UP[off]; GRAD[off] = GRADP[off];
     }

@@ -202,6 +202,42 @@ static int sparse_zl_setup(Ctx& c)
     MCML_HIP(hipMemcpyAsync(sp.csr_pos.p, cp.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c.stream));
     MCML_TRY(sp.row_start.ensure(sizeof(int) * (size_t)Q));
     MCML_HIP(hipMemcpyAsync(sp.row_start.p, start_of.data(), sizeof(int) * (size_t)Q, hipMemcpyHostToDevice, c.stream));
+    // the factored form: rows of Z' (CSR) and the end of each column of L
+    {
+        std::vector<int> zcnt(Q, 0), end_of(Q);
+        long nz = 0, nl = 0;
+        for (int b = 0; b < c.cov.B; ++b) {
+            const int d = c.cov.blocks[b].dim, m0 = c.cov.blocks[b].matstart;
+            for (int k = 0; k < d; ++k) end_of[m0 + k] = m0 + d;
+            nl += (long)d * (d + 1) / 2;
+        }
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < zw; ++k) if (c.h_zval[i + (size_t)k * n] != 0.0) { ++zcnt[c.h_zidx[i + (size_t)k * n]]; ++nz; }
+        std::vector<int> zptr(Q + 1, 0);
+        for (int q = 0; q < Q; ++q) zptr[q + 1] = zptr[q] + zcnt[q];
+        std::vector<int> zi((size_t)nz + 1), zfill(zptr.begin(), zptr.end() - 1);
+        std::vector<double> zv((size_t)nz + 1);
+        for (int i = 0; i < n; ++i)                                    // ascending observation within a row
+            for (int k = 0; k < zw; ++k) {
+                const double z = c.h_zval[i + (size_t)k * n];
+                if (z == 0.0) continue;
+                const int t = zfill[c.h_zidx[i + (size_t)k * n]]++;
+                zi[t] = i; zv[t] = z;
+            }
+        MCML_TRY(sp.zcsr_ptr.ensure(sizeof(int) * (size_t)(Q + 1))); MCML_TRY(sp.zcsr_i.ensure(sizeof(int) * (size_t)(nz + 1)));
+        MCML_TRY(sp.zcsr_val.ensure(sizeof(double) * (size_t)(nz + 1))); MCML_TRY(sp.row_end.ensure(sizeof(int) * (size_t)Q));
+        MCML_HIP(hipMemcpyAsync(sp.zcsr_ptr.p, zptr.data(), sizeof(int) * (size_t)(Q + 1), hipMemcpyHostToDevice, c.stream));
+        MCML_HIP(hipMemcpyAsync(sp.zcsr_i.p, zi.data(), sizeof(int) * (size_t)nz, hipMemcpyHostToDevice, c.stream));
+        MCML_HIP(hipMemcpyAsync(sp.zcsr_val.p, zv.data(), sizeof(double) * (size_t)nz, hipMemcpyHostToDevice, c.stream));
+        MCML_HIP(hipMemcpyAsync(sp.row_end.p, end_of.data(), sizeof(int) * (size_t)Q, hipMemcpyHostToDevice, c.stream));
+        sp.nnz_z = nz; sp.nnz_l = nl;
+        // entries gathered per chain and leapfrog step: nnz(ZL) against nnz(Z) + nnz(L) + the extra pass over Q
+        sp.factored = 4 * (nz + nl + 2L * Q) < 3 * nnz;
+        if (const char* e = getenv("GLMMR_MCML_ZL")) {
+            if (!strcmp(e, "factored")) sp.factored = true;
+            if (!strcmp(e, "product")) sp.factored = false;
+        }
+    }
     MCML_HIP(hipStreamSynchronize(c.stream));
     sp.W = W; sp.nnz = nnz; sp.possible = true;
     return MCML_OK;

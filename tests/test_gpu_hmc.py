@@ -129,23 +129,27 @@ def test_many_chains_recover_gaussian_posterior(orc):
 
 
 def test_sparse_and_dense_zl_operators_agree(monkeypatch):
-    """configs 1/4/5: the ELL/CSR ZL operator and the dense MFMA GEMMs are the same sampler"""
+    """configs 1/4/5: the ELL/CSR ZL operator (as the product ZL and as the two factors Z, L applied in turn,
+    hmc_cm.h) and the dense MFMA GEMMs are the same sampler"""
     from glmmrmcml_amd import api
     for gen, kw in ((synth.stepped_wedge, dict(ncl=9, nt=6, nind=12)), (synth.longitudinal, dict(nsubj=50, nvisit=4)),
-                    (synth.stepped_wedge, dict(ncl=7, nt=5, nind=40))):      # long rows of ZL' (config 4's regime)
+                    (synth.stepped_wedge, dict(ncl=7, nt=5, nind=40)),       # long rows of ZL' (config 4's regime)
+                    (synth.cluster_rct, dict(ncl=6, nt=4, nind=5, family="poisson"))):
         d = gen(**kw)
         out = {}
-        for mode in ("sparse", "dense"):
-            if mode == "dense":
-                monkeypatch.setenv("GLMMR_MCML_ZL", "dense")
-            else:
-                monkeypatch.delenv("GLMMR_MCML_ZL", raising=False)
+        for mode in ("product", "factored", "dense"):
+            monkeypatch.setenv("GLMMR_MCML_ZL", mode)
             with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"]) as ctx:
                 ctx.update_L(d["theta"])
                 diag, flags, probs = ctx.hmc_sample(d["beta"], 1.0, 15, 24, 0.4, 8, 0.9, seed=77, chains=12,
                                                     want_trace=True)
-                out[mode] = (ctx.get_u(), flags.copy(), probs.copy())
+                V = np.random.default_rng(5).normal(size=(d["Q"], 3)) * 0.5
+                lp, G = ctx.log_prob_grad(d["beta"], 1.0, V)
+                out[mode] = (ctx.get_u(), flags.copy(), probs.copy(), lp, G)
         monkeypatch.delenv("GLMMR_MCML_ZL", raising=False)
-        assert np.array_equal(out["sparse"][1], out["dense"][1])
-        assert np.abs(out["sparse"][2] - out["dense"][2]).max() < 1e-9
-        assert np.abs(out["sparse"][0] - out["dense"][0]).max() < 1e-8
+        for mode in ("factored", "dense"):
+            assert np.array_equal(out["product"][1], out[mode][1]), mode
+            assert np.abs(out["product"][2] - out[mode][2]).max() < 1e-9, mode
+            assert np.abs(out["product"][0] - out[mode][0]).max() < 1e-8, mode
+            assert np.abs(out["product"][3] - out[mode][3]).max() < 1e-11 * np.abs(out["product"][3]).max(), mode
+            assert np.abs(out["product"][4] - out[mode][4]).max() < 1e-11 * max(1.0, np.abs(out["product"][4]).max()), mode

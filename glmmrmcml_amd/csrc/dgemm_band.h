@@ -155,13 +155,7 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
     // epilogue stores -- vector memory completes in order, its `s_waitcnt vmcnt(0)` drains every store before
     // the next item's first LDS-DMA can even be issued: measured 471 vs 428 us per launch at 1024 chains.
     const int it0 = bp.wg_ptr[pw], it1 = bp.wg_ptr[pw + 1];
-#ifdef BD_EXP_TWOPASS
-    for (int it_ = 0; it_ < 2; ++it_) {
-        const int it = it0 + it_;
-        if (it >= it1) break;
-#else
     for (int it = it0; it < it1; ++it) {
-#endif
         BandItem item;
 #if defined(__HIP_DEVICE_COMPILE__)
         {
@@ -329,11 +323,7 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
                 st = st + 1; if (st >= BD_STAGES) st = 0;
             }
         }
-#ifdef BD_EXP_NOELSE
-        if (true) {
-#else
         if (item.slot < 0) {
-#endif
             epi(acc, m0, n0 + wave * 16, lane, p.M, p.N, band);
         } else {
             // raw accumulator tile in register order: element (wave, i, r, lane) -- each store instruction

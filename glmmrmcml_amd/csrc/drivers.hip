@@ -16,6 +16,7 @@
 #include "../../include/glmmr_mcml_c.h"
 #include "ctx.h"
 #include "optim.h"
+#include "trace.h"
 #include <cmath>
 #include <random>
 
@@ -177,7 +178,11 @@ int drv_optim(Ctx& c, const double* start, int nstart, int trace, int mcnr, cons
     MCML_REQUIRE(start && nstart >= P + R + (is_gaussian(c.flink) ? 1 : 0), "start has %d values, need %d", nstart, P + R + (is_gaussian(c.flink) ? 1 : 0));
     MCML_REQUIRE(c.mcols > 0, "no samples u set");
     McmlOptim mc(c, start, trace, e ? e->maxfun : 0, 1.0);      // model built with var_par = 1 (mcml_optim.cpp:51)
-    if (!mcnr) MCML_TRY(mc.l_optim()); else MCML_TRY(mc.mcnr());
+    {
+        PhaseRange r("mcml:beta-step");
+        if (!mcnr) MCML_TRY(mc.l_optim()); else MCML_TRY(mc.mcnr());
+    }
+    PhaseRange r("mcml:theta-step");
     MCML_TRY(mc.d_optim());
     memcpy(beta, mc.beta.data(), sizeof(double) * P);
     memcpy(theta, mc.theta.data(), sizeof(double) * R);
@@ -250,12 +255,21 @@ int drv_full(Ctx& c, const double* start, int nstart, int mcnr, int m, int maxit
     ho.target_accept = target_accept; ho.chains = chains; ho.chain_offset = c.rank * chains;
     while (maxdiff > tol && iter <= maxiter) {                                 // :83
         glmmr_mcml_hmc_diag dg{};
-        MCML_TRY(hmc_sample(c, beta.data(), var_par, &ho, seed, (uint32_t)iter, nullptr, nullptr, nullptr,
-                            nullptr, &dg, nullptr));                           // :92
+        {
+            PhaseRange r("mcml:sample");
+            MCML_TRY(hmc_sample(c, beta.data(), var_par, &ho, seed, (uint32_t)iter, nullptr, nullptr, nullptr,
+                                nullptr, &dg, nullptr));                       // :92
+        }
         if (last_diag) *last_diag = dg;
         mc.model_var_par = var_par;
-        if (!mcnr) MCML_TRY(mc.l_optim()); else MCML_TRY(mc.mcnr());           // :95-99
-        MCML_TRY(mc.d_optim());                                                // :101
+        {
+            PhaseRange r("mcml:beta-step");
+            if (!mcnr) MCML_TRY(mc.l_optim()); else MCML_TRY(mc.mcnr());       // :95-99
+        }
+        {
+            PhaseRange r("mcml:theta-step");
+            MCML_TRY(mc.d_optim());                                            // :101
+        }
         const std::vector<double>& nb = mc.beta; const std::vector<double>& nt = mc.theta;
         double new_var_par = 1;
         if (is_gaussian(c.flink)) new_var_par = mc.sigma;                      // :105
@@ -267,6 +281,7 @@ int drv_full(Ctx& c, const double* start, int nstart, int mcnr, int m, int maxit
         if (maxdiff < tol) converged = true;                                   // :113
         beta = nb; theta = nt; var_par = new_var_par;
         if (!converged) {                                                      // :119-126
+            PhaseRange r("mcml:refresh");
             MCML_TRY(mvn_gen_L(c, theta.data(), true));
             MCML_TRY(model_update_beta(c, beta.data()));
             MCML_TRY(model_update_L(c));

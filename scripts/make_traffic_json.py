@@ -22,7 +22,8 @@ fd, wd, n, chains, dz, build = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(s
 fe, wr = collect(fd, "FETCH_SIZE"), collect(wd, "WRITE_SIZE")
 detail = {}
 for k in sorted(set(fe) | set(wr)):
-    if not any(p in k for p in ("dgemm_band_kernel", "k_band_reduce", "dgemm_dlds", "k_sp_forward", "k_sp_backward")):
+    if not any(p in k for p in ("dgemm_band_kernel", "k_band_reduce", "dgemm_dlds", "k_cm_forward", "k_cm_backward", "k_cm_Lrow", "k_cm_Lcol",
+                                  "k_cm_logprob", "k_cm_propose", "k_cm_commit")):
         continue
     f, nf = fe.get(k, [0.0, 0]); w, nw = wr.get(k, [0.0, 0])
     detail[k[:120]] = {"launches": nf, "fetch_bytes_per_launch_x2": 2 * 1024 * f / max(nf, 1),
@@ -40,6 +41,6 @@ out = {"n": n, "chains": chains, "dense_z": bool(dz), "build": build,
                  "and backward kernels",
        "hbm_bytes_per_launch_banded": avg(lambda k: "dgemm_band_kernel" in k),
        "hbm_bytes_per_launch_dense": avg(lambda k: "dgemm_dlds" in k),
-       "hbm_bytes_per_launch_sparse": avg(lambda k: "k_sp_" in k),
+       "hbm_bytes_per_launch_sparse": avg(lambda k: "k_cm_forward" in k or "k_cm_backward" in k),
        "kernels": detail}
 print(json.dumps(out, indent=1))

@@ -170,3 +170,24 @@ def test_simlik_sparse_and_hess_sparse_vs_oracle(orc):
     with pytest.raises(_lib.McmlError):
         api.mcml_simlik_sparse(d["cov"], d["data"], d["eff_range"], D.indptr, bad, d["Z"], d["X"], d["y"], u,
                                d["family"], d["link"], d["start"])
+
+
+def test_phase_ranges_with_roctx_enabled():
+    """GLMMR_MCML_ROCTX=1: the driver opens roctx ranges around sample / beta-step / theta-step / refresh
+    (csrc/trace.h); outside a profiler they are no-ops and the fit is the same fit"""
+    import json, os, subprocess, sys
+    code = ("import json, numpy as np\n"
+            "from glmmrmcml_amd import api, synth\n"
+            "d = synth.cluster_rct(ncl=6, nt=3, nind=5, seed=3)\n"
+            "g = api.mcml_full(d['cov'], d['data'], d['eff_range'], d['Z'], d['X'], d['y'], d['family'], d['link'],\n"
+            "                  d['start'], mcnr=True, m=16, maxiter=2, warmup=10, tol=1e-12, verbose=False, lambda_=0.3,\n"
+            "                  maxsteps=6, target_accept=0.9, seed=7, chains=4)\n"
+            "print(json.dumps([g['beta'].tolist(), g['theta'].tolist()]))\n")
+    out = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, GLMMR_MCML_ROCTX=flag)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[flag] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["0"] == out["1"]

@@ -44,6 +44,17 @@ class HmcDiag(C.Structure):
                 ("max_e", C.c_double), ("max_steps_used", C.c_int), ("leapfrog_total", C.c_longlong)]
 
 
+class NutsOpts(C.Structure):
+    _fields_ = [("warmup", C.c_int), ("nsamp", C.c_int), ("max_treedepth", C.c_int), ("adapt_delta", C.c_double),
+                ("stepsize", C.c_double), ("chains", C.c_int), ("chain_offset", C.c_int)]
+
+
+class NutsDiag(C.Structure):
+    _fields_ = [("mean_e", C.c_double), ("min_e", C.c_double), ("max_e", C.c_double), ("divergent", C.c_longlong),
+                ("treedepth_hits", C.c_longlong), ("batched_leapfrogs", C.c_longlong),
+                ("stepsize_search_leapfrogs", C.c_longlong)]
+
+
 def rccl_unique_id():
     """128 opaque bytes from ncclGetUniqueId: made on rank 0, handed to every rank's Context.comm_init_rccl"""
     buf = (C.c_ubyte * 128)()
@@ -209,6 +220,28 @@ class Context:
             return diag, flags, probs
         return diag
 
+    def nuts_sample(self, beta, var_par, warmup, nsamp, seed, chains=1, chain_offset=0, iter_idx=0, max_treedepth=10,
+                    adapt_delta=0.8, stepsize=1.0, want_trace=False):
+        """the sampler that stands where the reference calls Stan (gen_u_samples.R, inst/stan): csrc/nuts.h"""
+        beta = _f(beta).ravel()
+        o = NutsOpts(warmup, nsamp, max_treedepth, adapt_delta, stepsize, chains, chain_offset)
+        d = NutsDiag()
+        total = warmup + -(-nsamp // chains)
+        c_ip_ = C.POINTER(C.c_int)
+        tr = None
+        if want_trace:
+            tr = dict(depth=np.zeros((chains, total), dtype=np.int32, order="F"),
+                      nleap=np.zeros((chains, total), dtype=np.int32, order="F"),
+                      eps=np.zeros((chains, total), order="F"), accept=np.zeros((chains, total), order="F"))
+        ncols = C.c_int()
+        _lib.check(_lib.lib().glmmr_mcml_ctx_nuts_sample(
+            self._h, _p(beta), C.c_double(var_par), C.byref(o), C.c_uint64(seed), C.c_uint32(iter_idx),
+            None if tr is None else tr["depth"].ctypes.data_as(c_ip_), None if tr is None else tr["nleap"].ctypes.data_as(c_ip_),
+            None if tr is None else _p(tr["eps"]), None if tr is None else _p(tr["accept"]), C.byref(d), C.byref(ncols)))
+        self.mcols = ncols.value
+        diag = dict(mean_e=d.mean_e, min_e=d.min_e, max_e=d.max_e, divergent=d.divergent, treedepth_hits=d.treedepth_hits,
+                    batched_leapfrogs=d.batched_leapfrogs, stepsize_search_leapfrogs=d.stepsize_search_leapfrogs)
+        return (diag, tr) if want_trace else diag
 
     # -- drivers on the resident context
     def _ext(self, seed, chains, maxfun):
@@ -368,6 +401,22 @@ def mcmc_sample(Z, L, X, y, beta, family, link, warmup, nsamp, lambda_, var_par=
                                           C.c_double(lambda_), C.c_double(var_par), int(trace), int(refresh),
                                           int(maxsteps), C.c_double(target_accept), C.byref(e), _p(out), Q,
                                           C.byref(nc)))
+    return out[:, :nc.value]
+
+
+def gen_u_samples(y, X, Z, L, beta, family, link, sigma=1.0, warmup_iter=100, m=100, seed=0, chains=1,
+                  max_treedepth=10, adapt_delta=0.8):
+    """gen_u_samples(y, X, Z, L, beta, family, sigma, warmup_iter, m) -> Q x m matrix of u = L gamma
+    (R/gen_u_samples.R:38-69; the NUTS sampler of csrc/nuts.h stands where cmdstanr is called)"""
+    Z = _f(Z); Lm = _f(L); X = _f(X); y = _f(y).ravel(); beta = _f(beta).ravel()
+    n, Q = Z.shape
+    ncol = chains * -(-int(m) // chains)
+    out = np.zeros((Q, ncol), order="F"); nc = C.c_int()
+    e = Ext(int(seed), int(chains), 0, 0)
+    o = NutsOpts(int(warmup_iter), int(m), int(max_treedepth), float(adapt_delta), 0.0, int(chains), 0)
+    _lib.check(_lib.lib().glmmr_mcml_gen_u_samples(_p(Z), _p(Lm), _p(X), _p(y), n, Q, X.shape[1], _p(beta), family.encode(),
+                                                   link.encode(), C.c_double(sigma), int(warmup_iter), int(m), C.byref(o),
+                                                   C.byref(e), _p(out), Q, C.byref(nc)))
     return out[:, :nc.value]
 
 

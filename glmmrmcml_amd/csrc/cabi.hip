@@ -10,6 +10,9 @@ namespace mcml {
 int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_opts* o, uint64_t seed,
                uint32_t iter_idx, const double* inj_init, const double* inj_mom, uint8_t* flags_out,
                double* probs_out, glmmr_mcml_hmc_diag* diag, int* ncols_out);
+int nuts_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_nuts_opts* o, uint64_t seed, uint32_t iter_idx,
+                int* depth_out, int* nleap_out, double* eps_out, double* accept_out, glmmr_mcml_nuts_diag* diag,
+                int* ncols_out);
 }
 
 static int flink_of(const char* family, const char* link)
@@ -249,6 +252,17 @@ extern "C" int glmmr_mcml_ctx_hmc_sample(glmmr_mcml_ctx* h, const double* beta, 
     MCML_HIP(hipSetDevice(h->c.device));
     return hmc_sample(h->c, beta, var_par, opts, seed, iter_idx, inj_init, inj_mom, flags_out, probs_out,
                       diag, ncols_out);
+}
+
+extern "C" int glmmr_mcml_ctx_nuts_sample(glmmr_mcml_ctx* h, const double* beta, double var_par,
+                                          const glmmr_mcml_nuts_opts* opts, uint64_t seed, uint32_t iter_idx,
+                                          int* depth_out, int* nleap_out, double* eps_out, double* accept_out,
+                                          glmmr_mcml_nuts_diag* diag, int* ncols_out)
+{
+    MCML_REQUIRE(h && beta && opts, "nuts_sample: null argument");
+    MCML_HIP(hipSetDevice(h->c.device));
+    return nuts_sample(h->c, beta, var_par, opts, seed, iter_idx, depth_out, nleap_out, eps_out, accept_out, diag,
+                       ncols_out);
 }
 
 extern "C" int glmmr_mcml_dbg_log_prob_grad(glmmr_mcml_ctx* h, const double* beta, double var_par,
@@ -612,5 +626,26 @@ extern "C" int glmmr_mcml_mcmc_sample(const double* Z, const double* L, const do
     uint64_t seed = (ext && ext->seed) ? ext->seed : 0;
     if (!seed) { std::random_device rd; seed = ((uint64_t)rd() << 32) | rd(); }
     MCML_TRY(glmmr_mcml_ctx_hmc_sample(g.h, beta, var_par, &ho, seed, 0, nullptr, nullptr, nullptr, nullptr, nullptr, ncols));
+    return glmmr_mcml_get_u(g.h, samples, lds);
+}
+
+extern "C" int glmmr_mcml_gen_u_samples(const double* Z, const double* L, const double* X, const double* y, int n, int Q,
+                                        int P, const double* beta, const char* family, const char* link, double sigma,
+                                        int warmup_iter, int m, const glmmr_mcml_nuts_opts* opts, const glmmr_mcml_ext* ext,
+                                        double* samples, int lds, int* ncols)
+{
+    MCML_REQUIRE(Z && L && X && y && beta && samples, "gen_u_samples: null argument");
+    glmmr_mcml_problem p{};
+    p.Z = Z; p.X = X; p.y = y; p.n = n; p.Q = Q; p.P = P; p.family = family; p.link = link;
+    CtxGuard g;
+    MCML_TRY(open_ctx(&p, ext, g));
+    MCML_TRY(glmmr_mcml_ctx_set_L(g.h, L, Q));
+    glmmr_mcml_nuts_opts no{};
+    if (opts) no = *opts;
+    no.warmup = warmup_iter; no.nsamp = m;
+    if (no.chains <= 0) no.chains = (ext && ext->chains > 0) ? ext->chains : 1;      // gen_u_samples.R:59: chains = 1
+    uint64_t seed = (ext && ext->seed) ? ext->seed : 0;
+    if (!seed) { std::random_device rd; seed = ((uint64_t)rd() << 32) | rd(); }
+    MCML_TRY(glmmr_mcml_ctx_nuts_sample(g.h, beta, sigma, &no, seed, 0, nullptr, nullptr, nullptr, nullptr, nullptr, ncols));
     return glmmr_mcml_get_u(g.h, samples, lds);
 }

@@ -28,6 +28,14 @@ struct HmcState {
     DevMat LX, ZS;              // factored operator (SparseZL::factored): L X and Z' S, C x Q
 };
 
+// No-U-Turn sampler (nuts.h): edges, tree, node under construction and one stored node per tree level (Q x C each),
+// per-chain scalars, partial sums
+constexpr int NUTS_MAXD = 12;                       // deepest tree supported (Stan's default max_treedepth: 10)
+struct NutsState {
+    DevMat vecs[11 + 3 * (NUTS_MAXD + 1)];
+    DevBuf chain, part;
+};
+
 // ZL = Z L held as padded-CSR (ELL) rows plus its transpose in CSR: used by the sampler (chain-major state, hmc_cm.h)
 // instead of the dense n x Q products when Z is indicator-like and every covariance block is
 // diagonal or small, so that a row of ZL has only a few nonzeros (configs 1, 4, 5): the two
@@ -137,6 +145,7 @@ struct Ctx {
 
     // sampler
     HmcState hmc;
+    NutsState nuts;
     KernelProf prof;
 
     // distribution

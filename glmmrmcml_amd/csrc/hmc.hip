@@ -781,3 +781,5 @@ int hmc_dbg_log_prob_grad(Ctx& c, const double* beta, double var_par, const doub
 }
 
 }  // namespace mcml
+
+#include "nuts.h"

@@ -242,7 +242,8 @@ class ModelMCML:
     def MCML(self, y, start=None, se_method="approx", method="mcnr", sim_lik_step=False, verbose=True, tol=1e-2,
              max_iter=30, sparse=False, sampler="full", options=None, seed=0, chains=1):
         """ModelMCML$MCML (R6ModelExtMCML.R:103-594).  sampler: "full" = the usestan = FALSE branch (mcml_full);
-        "stepwise" = the usestan = TRUE loop with mcmc_sample standing in for Stan.  seed / chains are the build's
+        "stepwise" = the usestan = TRUE loop with mcmc_sample standing in for Stan, "nuts" = the same loop with
+        gen_u_samples (the build's No-U-Turn sampler, csrc/nuts.h) in Stan's place.  seed / chains are the build's
         additions (0 = random_device, 1 chain = the reference)."""
         if se_method not in ("lik", "robust", "approx", "none"):
             raise ValueError("se.method should be 'lik', 'robust', 'approx', or 'none'")
@@ -280,7 +281,7 @@ class ModelMCML:
             theta[par["cov"]] = res["theta"]
             not_conv = not res["converged"]
             dsamps = np.asarray(res["u"])
-        elif sampler == "stepwise":
+        elif sampler in ("stepwise", "nuts"):
             with be.Context(self.cov, self.data, self.eff_range) as ctx:
                 L = ctx.gen_D(theta[par["cov"]], chol=True)
             thetanew = np.ones_like(theta)
@@ -288,11 +289,16 @@ class ModelMCML:
             while np.any(np.abs(theta - thetanew) > tol) and it <= max_iter:
                 it += 1
                 thetanew = theta.copy()
-                dsamps = be.mcmc_sample(self.Z, L, self.X, y, thetanew[par["b"]], self.family, self.link, mo["warmup"],
-                                        mo["samps"], mo["lambda_"], var_par=thetanew[par["sig"]], trace=trace,
-                                        refresh=mo["refresh"], maxsteps=mo["maxsteps"],
-                                        target_accept=mo["target_accept"], seed=(seed + it if seed else 0),
-                                        chains=chains)
+                if sampler == "nuts":                            # mod$sample(...) + L %*% t(draws), :246-254
+                    dsamps = be.gen_u_samples(y, self.X, self.Z, L, thetanew[par["b"]], self.family, self.link,
+                                              sigma=thetanew[par["sig"]], warmup_iter=mo["warmup"], m=mo["samps"],
+                                              seed=(seed + it if seed else 0), chains=chains)
+                else:
+                    dsamps = be.mcmc_sample(self.Z, L, self.X, y, thetanew[par["b"]], self.family, self.link, mo["warmup"],
+                                            mo["samps"], mo["lambda_"], var_par=thetanew[par["sig"]], trace=trace,
+                                            refresh=mo["refresh"], maxsteps=mo["maxsteps"],
+                                            target_accept=mo["target_accept"], seed=(seed + it if seed else 0),
+                                            chains=chains)
                 if sparse:
                     fit = be.mcml_optim_sparse(*self._ddata(), pattern[0], pattern[1], self.Z, self.X, y, dsamps,
                                                self.family, self.link, theta.copy(), trace=trace, mcnr=(method == "mcnr"),
@@ -314,7 +320,7 @@ class ModelMCML:
                                                                           np.max(np.abs(theta - thetanew))))
             not_conv = it >= max_iter or bool(np.any(np.abs(theta - thetanew) > tol))
         else:
-            raise ValueError("sampler should be 'full' or 'stepwise'")
+            raise ValueError("sampler should be 'full', 'stepwise' or 'nuts'")
         if not_conv and not no_warnings:
             warnings.append("algorithm not converged")
         if sim_lik_step:

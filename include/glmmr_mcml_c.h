@@ -135,6 +135,36 @@ int glmmr_mcml_ctx_hmc_sample(glmmr_mcml_ctx* ctx, const double* beta, double va
                               const double* inj_init, const double* inj_mom, uint8_t* flags_out,
                               double* probs_out, glmmr_mcml_hmc_diag* diag, int* ncols_out);
 
+/* No-U-Turn sampler standing where the reference calls Stan through cmdstanr (R/gen_u_samples.R:38-69,
+ * R6ModelExtMCML.R:234-257 with inst/stan/mcml_*.stan: gamma ~ std_normal(), y ~ family(Xb + Z L gamma)).
+ * Stan's multinomial NUTS with the generalised U-turn criterion and dual-averaging step size, metric = unit_e
+ * (csrc/nuts.h lists what is and is not reproduced).  Stan's defaults apply where a field is 0. */
+typedef struct glmmr_mcml_nuts_opts {
+    int    warmup;          /* iter_warmup */
+    int    nsamp;           /* iter_sampling: draws wanted in total */
+    int    max_treedepth;   /* 0 -> 10 */
+    double adapt_delta;     /* 0 -> 0.8 */
+    double stepsize;        /* initial step size before the init_stepsize search; 0 -> 1 */
+    int    chains;          /* C chains x ceil(nsamp/C) draws each; u is Q x C*ceil(nsamp/C) (no column 0) */
+    int    chain_offset;    /* global id of this rank's first chain */
+} glmmr_mcml_nuts_opts;
+
+typedef struct glmmr_mcml_nuts_diag {
+    double    mean_e, min_e, max_e;          /* step sizes after adaptation */
+    long long divergent;                     /* transitions that ended in a divergence (all chains, warm-up included) */
+    long long treedepth_hits;                /* transitions stopped by max_treedepth */
+    long long batched_leapfrogs;             /* leapfrog steps launched (each advances every growing chain) */
+    long long stepsize_search_leapfrogs;
+} glmmr_mcml_nuts_diag;
+
+/* Fills the context's samples with L * gamma like glmmr_mcml_ctx_hmc_sample.  depth_out / nleap_out (int) and
+ * eps_out / accept_out (double), each chains x (warmup + ceil(nsamp/chains)), nullable: tree depth, leapfrog count,
+ * step size used and mean acceptance statistic of every transition. */
+int glmmr_mcml_ctx_nuts_sample(glmmr_mcml_ctx* ctx, const double* beta, double var_par,
+                               const glmmr_mcml_nuts_opts* opts, uint64_t seed, uint32_t iter_idx,
+                               int* depth_out, int* nleap_out, double* eps_out, double* accept_out,
+                               glmmr_mcml_nuts_diag* diag, int* ncols_out);
+
 /* ------------------------------------------------------------------------- */
 /* Mirrors of the Rcpp exports (host buffers in, host buffers out)            */
 /* ------------------------------------------------------------------------- */
@@ -146,6 +176,13 @@ typedef struct glmmr_mcml_ext {
     int      maxfun;    /* objective evaluations per optimiser call; 0 = 10000 (minqa default) */
     int      device;    /* HIP device ordinal */
 } glmmr_mcml_ext;
+
+/* gen_u_samples(y, X, Z, L, beta, family, sigma, warmup_iter, m) -> Q x m      -- R/gen_u_samples.R:38-69
+ * (the R function takes a family object; here family / link strings as in the other exports) */
+int glmmr_mcml_gen_u_samples(const double* Z, const double* L, const double* X, const double* y, int n, int Q, int P,
+                             const double* beta, const char* family, const char* link, double sigma, int warmup_iter,
+                             int m, const glmmr_mcml_nuts_opts* opts, const glmmr_mcml_ext* ext, double* samples,
+                             int lds, int* ncols);
 
 /* columns of u a sampler call returns for m samples: m + 1 for one chain
  * (mhmcmc.h:126), chains * ceil(m / chains) otherwise */

@@ -1,0 +1,86 @@
+"""GPU parity of the No-U-Turn sampler (csrc/nuts.h) -- the sampler that stands where the reference calls Stan
+(R/gen_u_samples.R:38-69, inst/stan/mcml_*.stan) -- against oracle/nuts.py.
+
+PARITY UNPINNED: cmdstan does not exist in this image and the reference holds no Stan output.  The oracle restates the
+published algorithm with the device's random streams; every transition's tree depth and leapfrog count must be
+identical, step sizes within 1e-9 relative and draws within 1e-7 (f64, different summation orders; no decision in these
+seeded cases sits within rounding of its threshold).  The exact gaussian posterior is the known answer."""
+import numpy as np
+import pytest
+
+from glmmrmcml_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(orc, d, api):
+    ctx = api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"])
+    ctx.update_L(d["theta"])
+    Lo = orc.gen_D(d["cov"], d["data"], d["eff_range"], d["theta"], chol=True)
+    return ctx, d["Z"] @ Lo, d["X"] @ d["beta"], orc.flink(d["family"], d["link"]), Lo
+
+
+CASES = [(synth.geospatial, dict(n=96), 0.9),                                  # dense ZL: column-major state, MFMA products
+         (synth.cluster_rct, dict(ncl=6, nt=4, nind=5, family="poisson"), 1.0),  # sparse ZL as a product: chain-major state
+         (synth.stepped_wedge, dict(ncl=6, nt=4, nind=30), 1.0)]               # sparse ZL as two factors
+
+
+@pytest.mark.parametrize("gen,kw,vp", CASES)
+def test_chains_match_oracle_transition_by_transition(orc, gen, kw, vp):
+    from glmmrmcml_amd import api
+    from oracle import nuts
+    d = gen(**kw)
+    ctx, ZL, xb, fl, Lo = _setup(orc, d, api)
+    Cn, warm, nsamp, seed, it, md = 4, 14, 12, 20240607, 3, 6
+    diag, tr = ctx.nuts_sample(d["beta"], vp, warm, nsamp, seed, chains=Cn, chain_offset=5, iter_idx=it, max_treedepth=md,
+                               want_trace=True)
+    u = ctx.get_u()
+    dpc = 3
+    assert u.shape == (d["Q"], Cn * dpc)
+    ndiv = nhit = 0
+    for c in range(Cn):
+        so, to, dg = nuts.nuts_chain(xb, ZL, d["y"], vp, fl, warm, dpc, seed, chain_id=5 + c, iter_idx=it, max_treedepth=md)
+        assert np.array_equal(tr["depth"][c], to["depth"]), (c, tr["depth"][c], to["depth"])
+        assert np.array_equal(tr["nleap"][c], to["nleap"]), (c, tr["nleap"][c], to["nleap"])
+        assert np.abs(tr["eps"][c] / to["eps"] - 1).max() < 1e-9
+        assert np.abs(tr["accept"][c] - to["accept"]).max() < 1e-9
+        uo = Lo @ so
+        assert np.abs(u[:, c * dpc:(c + 1) * dpc] - uo).max() < 1e-7 * max(1.0, np.abs(uo).max())
+        ndiv += to["ndiv"]; nhit += to["nhit"]
+    assert diag["divergent"] == ndiv and diag["treedepth_hits"] == nhit
+    assert tr["depth"].max() >= 2                       # the trees did grow
+    ctx.close()
+
+
+def test_many_chains_recover_gaussian_posterior(orc):
+    """gaussian-identity: the posterior of gamma is N(mu*, S*) exactly (SURVEY 8c KAT 5)"""
+    from glmmrmcml_amd import api
+    d = synth.geospatial(40, seed=21)
+    ctx, ZL, xb, fl, Lo = _setup(orc, d, api)
+    S = np.linalg.inv(np.eye(40) + ZL.T @ ZL / d["sigma"] ** 2)
+    mu = S @ ZL.T @ (d["y"] - xb) / d["sigma"] ** 2
+    diag = ctx.nuts_sample(d["beta"], d["sigma"], 60, 1024, seed=5, chains=1024)
+    u = ctx.get_u()
+    assert u.shape == (40, 1024)
+    v = np.linalg.solve(Lo, u)
+    se = np.sqrt(np.diag(S) / 1024)
+    assert np.all(np.abs(v.mean(1) - mu) < 5 * se)
+    assert np.abs(np.cov(v) - S).max() < 0.12 * np.abs(S).max()
+    assert diag["divergent"] < 0.02 * 1024 * 61 and 1e-3 < diag["mean_e"] < 10      # the first warm-up steps may diverge
+    ctx.close()
+
+
+def test_gen_u_samples_export(orc):
+    """gen_u_samples(y, X, Z, L, beta, family, sigma, warmup_iter, m) (R/gen_u_samples.R:38-69): Q x m draws of
+    u = L gamma, the same draws as the context-level call with the same seed"""
+    from glmmrmcml_amd import api
+    d = synth.cluster_rct(ncl=6, nt=3, nind=6, seed=4)
+    L = orc.gen_D(d["cov"], d["data"], d["eff_range"], d["theta"], chol=True)
+    with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"]) as ctx:
+        ctx.set_L(L)                                    # the export takes L as a matrix: the dense operator
+        ctx.nuts_sample(d["beta"], 1.0, 20, 16, seed=99, chains=1)
+        want = ctx.get_u()
+    got = api.gen_u_samples(d["y"], d["X"], d["Z"], L, d["beta"], d["family"], d["link"], 1.0, warmup_iter=20, m=16, seed=99)
+    assert got.shape == (d["Q"], 16) and np.isfinite(got).all()
+    assert np.abs(got - want).max() < 1e-9
+    assert np.abs(got).max() > 0

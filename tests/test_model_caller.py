@@ -47,6 +47,10 @@ class FakeBackend:
         self._rec("mcmc_sample", a, k)
         return self.u
 
+    def gen_u_samples(self, *a, **k):
+        self._rec("gen_u_samples", a, k)
+        return self.u
+
     def mcml_optim(self, *a, **k):
         self._rec("mcml_optim", a, k)
         return dict(beta=np.full(self.P, 0.5), theta=np.full(self.R, 0.2), sigma=0.9)
@@ -136,6 +140,21 @@ def test_stepwise_loop_calls_sampler_then_optim_and_rebuilds_L_from_previous_the
     assert np.allclose(L1, np.eye(m.Z.shape[1]) * np.sqrt(0.35))
     assert np.allclose(L2, np.eye(m.Z.shape[1]) * np.sqrt(0.35))
     assert be.calls[1][2]["mcnr"] is True
+
+
+def test_nuts_loop_is_the_usestan_branch_with_gen_u_samples():
+    """usestan = TRUE (R6ModelExtMCML.R:234-257): data$Z = Z L, data$Xb from the current beta, data$sigma; the draws
+    come back as L %*% t(gamma) and go to mcml_optim"""
+    d, be, m = _model("gaussian")
+    fit = m.MCML(d["y"], sampler="nuts", verbose=False, max_iter=3, tol=1e-2, seed=5)
+    names = [c[0] for c in be.calls]
+    assert names[:2] == ["gen_u_samples", "mcml_optim"] and "mcmc_sample" not in names
+    a, k = be.calls[0][1], be.calls[0][2]
+    assert np.array_equal(a[0], d["y"]) and a[1] is m.X and a[2] is m.Z           # (y, X, Z, L, beta, family, link)
+    assert np.allclose(a[3], np.eye(m.Z.shape[1]) * np.sqrt(0.35))
+    assert a[5] == "gaussian" and k["warmup_iter"] == m.mcmc_options["warmup"] and k["m"] == m.mcmc_options["samps"]
+    assert k["sigma"] == pytest.approx(float(m._start(None)[0][-1])) and k["seed"] == 6
+    assert fit["converged"]
 
 
 def test_sparse_stepwise_uses_sparse_exports_and_ldl_factor():

@@ -18,6 +18,8 @@ typedef int (*reduce_fn)(void* user, double* dev_buf, int n);
 
 struct HmcState {
     int C = 0;                  // chains resident
+    int Cw = 0;                 // columns the two products and the log-density kernels process (= C; the No-U-Turn
+                                // sampler packs the chains whose trees still grow into the first Cw columns)
     DevMat V, R, UP, GRAD, GRADP;   // Q x C
     DevMat MU, S;               // n x C
     DevBuf chain;               // per-chain scalars, see hmc.hip

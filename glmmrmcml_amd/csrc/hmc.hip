@@ -410,7 +410,7 @@ __global__ void k_hmc_diag(ChainArrays ca, int C, double* out)
 static int hmc_alloc(Ctx& c, int C)
 {
     HmcState& h = c.hmc;
-    h.C = C;
+    h.C = C; h.Cw = C;
     h.cm = c.sp.active;
     if (h.cm) {
         // chain-major (hmc_cm.h): "rows" of the DevMat are the chains
@@ -448,11 +448,11 @@ template <class Epi>
 static int hmc_forward_launch(Ctx& c, const double* X, int ldx, const Epi& epi)
 {
     HmcState& h = c.hmc;
-    if (c.band_fwd && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
-        return launch_gemm_band(c.stream, c.plan_fwd, h.C, c.ZL.d(), c.ZL.ld, X, ldx, epi);
-    if (use_dlds() && dlds_applicable(c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
-        return launch_gemm_dlds(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
-    return launch_gemm<false>(c.stream, c.n, h.C, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
+    if (c.band_fwd && dlds_applicable(c.n, h.Cw, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
+        return launch_gemm_band(c.stream, c.plan_fwd, h.Cw, c.ZL.d(), c.ZL.ld, X, ldx, epi);
+    if (use_dlds() && dlds_applicable(c.n, h.Cw, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
+        return launch_gemm_dlds(c.stream, c.n, h.Cw, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
+    return launch_gemm<false>(c.stream, c.n, h.Cw, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
 }
 
 static int hmc_forward(Ctx& c, const double* X, int ldx, double var_par, bool store_mu = true, bool chain = false)
@@ -462,19 +462,19 @@ static int hmc_forward(Ctx& c, const double* X, int ldx, double var_par, bool st
     int rc;
     if (h.cm) {
         const int rpw = CM_FR;
-        dim3 grid((c.n + 4 * rpw - 1) / (4 * rpw), (h.C + 63) / 64);
+        dim3 grid((c.n + 4 * rpw - 1) / (4 * rpw), (h.Cw + 63) / 64);
         // factored operator: LX = L X first, then the rows of Z gather from LX
         int W = c.sp.W; const int* col = c.sp.ell_col.as<int>(); const double* val = c.sp.ell_val.d(); const double* Xin = X;
         if (c.sp.factored) {
-            hipLaunchKernelGGL(k_cm_Lrow, dim3((c.Q + 3) / 4, (h.C + 63) / 64), dim3(256), 0, c.stream, c.Q, h.C, h.V.ld,
+            hipLaunchKernelGGL(k_cm_Lrow, dim3((c.Q + 3) / 4, (h.Cw + 63) / 64), dim3(256), 0, c.stream, c.Q, h.Cw, h.V.ld,
                                c.sp.row_start.as<int>(), c.L.d(), c.L.ld, X, h.LX.d());
             W = c.z_width; col = c.z_idx.as<int>(); val = c.z_val.d(); Xin = h.LX.d();
         }
         if (c.flink == 12)
-            hipLaunchKernelGGL((k_cm_forward<true>), grid, dim3(256), 0, c.stream, c.n, h.C, h.V.ld, W, col, val, Xin, c.xb.d(),
+            hipLaunchKernelGGL((k_cm_forward<true>), grid, dim3(256), 0, c.stream, c.n, h.Cw, h.V.ld, W, col, val, Xin, c.xb.d(),
                                c.y.d(), c.flink, var_par, store_mu ? 1 : 0, h.MU.d(), h.S.d(), rpw);
         else
-            hipLaunchKernelGGL((k_cm_forward<false>), grid, dim3(256), 0, c.stream, c.n, h.C, h.V.ld, W, col, val, Xin, c.xb.d(),
+            hipLaunchKernelGGL((k_cm_forward<false>), grid, dim3(256), 0, c.stream, c.n, h.Cw, h.V.ld, W, col, val, Xin, c.xb.d(),
                                c.y.d(), c.flink, var_par, store_mu ? 1 : 0, h.MU.d(), h.S.d(), rpw);
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
     } else if (c.flink == 12)      // beta/logit: the digamma score is its own instantiation (glm.h)
@@ -504,29 +504,29 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
         const int m1 = f ? 2 : mode;
         const double post = glm_score_post(var_par, c.flink);
         if ((f ? c.sp.nnz_z : c.sp.nnz) >= 24L * c.Q) {          // long rows: a workgroup per (random effect, 64 chains)
-            const int ncb = (h.C + 63) / 64;
-            hipLaunchKernelGGL(k_cm_backward_long, dim3((c.Q * ncb + 7) / 8 * 8), dim3(256), 0, c.stream, c.Q, h.C, h.V.ld,
+            const int ncb = (h.Cw + 63) / 64;
+            hipLaunchKernelGGL(k_cm_backward_long, dim3((c.Q * ncb + 7) / 8 * 8), dim3(256), 0, c.stream, c.Q, h.Cw, h.V.ld,
                                ptr, ci, cv, h.S.d(), Xs, out, h.R.d(), h.UP.d(), ca.e, ca.steps, s, post, m1, ncb);
         } else {
             const int rpw = 2;
-            dim3 grid((c.Q + 4 * rpw - 1) / (4 * rpw), (h.C + 63) / 64);
-            hipLaunchKernelGGL(k_cm_backward, grid, dim3(256), 0, c.stream, c.Q, h.C, h.V.ld, ptr, ci, cv, h.S.d(), Xs, out,
+            dim3 grid((c.Q + 4 * rpw - 1) / (4 * rpw), (h.Cw + 63) / 64);
+            hipLaunchKernelGGL(k_cm_backward, grid, dim3(256), 0, c.stream, c.Q, h.Cw, h.V.ld, ptr, ci, cv, h.S.d(), Xs, out,
                                h.R.d(), h.UP.d(), ca.e, ca.steps, s, post, m1, rpw);
         }
         if (f)
-            hipLaunchKernelGGL(k_cm_Lcol, dim3((c.Q + 3) / 4, (h.C + 63) / 64), dim3(256), 0, c.stream, c.Q, h.C, h.V.ld,
+            hipLaunchKernelGGL(k_cm_Lcol, dim3((c.Q + 3) / 4, (h.Cw + 63) / 64), dim3(256), 0, c.stream, c.Q, h.Cw, h.V.ld,
                                c.sp.row_end.as<int>(), c.L.d(), c.L.ld, h.ZS.d(), Xs, G, h.R.d(), h.UP.d(), ca.e, ca.steps, s,
                                post, mode);
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
         c.prof.end(c.stream, slot);
         return rc;
     }
-    if (c.band_bwd && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
-        rc = launch_gemm_band(c.stream, c.plan_bwd, h.C, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
-    else if (use_dlds() && dlds_applicable(c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
-        rc = launch_gemm_dlds(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
+    if (c.band_bwd && dlds_applicable(c.Q, h.Cw, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
+        rc = launch_gemm_band(c.stream, c.plan_bwd, h.Cw, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
+    else if (use_dlds() && dlds_applicable(c.Q, h.Cw, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
+        rc = launch_gemm_dlds(c.stream, c.Q, h.Cw, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
     else
-        rc = launch_gemm<false>(c.stream, c.Q, h.C, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
+        rc = launch_gemm<false>(c.stream, c.Q, h.Cw, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
     c.prof.end(c.stream, slot);
     return rc;
 }
@@ -551,9 +551,9 @@ static int cm_logprob_partials(Ctx& c, const double* X, const double* R, double 
 {
     HmcState& h = c.hmc;
     const CmParts p = cm_parts(c);
-    const dim3 grid((h.C + 63) / 64, p.nchn + p.nchq);
+    const dim3 grid((h.Cw + 63) / 64, p.nchn + p.nchq);
 #define MCML_LP_LAUNCH(FL) hipLaunchKernelGGL((k_cm_logprob_partials<FL>), grid, dim3(256), 0, c.stream, h.MU.d(), X, R, h.V.ld, \
-                       c.n, c.Q, h.C, c.y.d(), var_par, c.flink, p.nchn, p.ll, p.lp, p.kin, p.ldp)
+                       c.n, c.Q, h.Cw, c.y.d(), var_par, c.flink, p.nchn, p.ll, p.lp, p.kin, p.ldp)
     switch (c.flink) {                       // the common families get their own instantiation
     case 1: MCML_LP_LAUNCH(1); break;        // poisson / log
     case 3: MCML_LP_LAUNCH(3); break;        // binomial / logit

@@ -33,7 +33,7 @@ namespace mcml {
 
 struct NutsChain {                                  // per-chain scalars (arrays of Cp)
     double *eps, *H0, *lw_tree, *lw_stack, *lp_new, *sum_acc, *xbar, *sbar, *mu, *dH;
-    int *active, *valid, *dir, *depth, *nleap, *counter, *ndiv, *accsub, *was, *hdir, *hdone, *nhit;
+    int *active, *valid, *dir, *depth, *nleap, *counter, *ndiv, *accsub, *was, *hdir, *hdone, *nhit, *slot;
     uint8_t* choose;                                // [NUTS_MAXD][Cp]
     uint32_t* gen;
     int Cp;
@@ -42,7 +42,7 @@ struct NutsChain {                                  // per-chain scalars (arrays
 static size_t nuts_chain_bytes(int C)
 {
     const size_t Cp = (size_t)round_up(C, 64);
-    return sizeof(double) * Cp * (10 + NUTS_MAXD + 1) + sizeof(int) * Cp * 13 + (size_t)NUTS_MAXD * Cp + 256;
+    return sizeof(double) * Cp * (10 + NUTS_MAXD + 1) + sizeof(int) * Cp * 14 + (size_t)NUTS_MAXD * Cp + 256;
 }
 static NutsChain nuts_chain(void* base, int C)
 {
@@ -55,9 +55,9 @@ static NutsChain nuts_chain(void* base, int C)
     int* i = reinterpret_cast<int*>(d + (10 + NUTS_MAXD + 1) * Cp);
     a.active = i; a.valid = i + Cp; a.dir = i + 2 * Cp; a.depth = i + 3 * Cp; a.nleap = i + 4 * Cp;
     a.counter = i + 5 * Cp; a.ndiv = i + 6 * Cp; a.accsub = i + 7 * Cp; a.was = i + 8 * Cp; a.hdir = i + 9 * Cp;
-    a.hdone = i + 10 * Cp; a.nhit = i + 11 * Cp;
-    a.gen = reinterpret_cast<uint32_t*>(i + 12 * Cp);
-    a.choose = reinterpret_cast<uint8_t*>(i + 13 * Cp);
+    a.hdone = i + 10 * Cp; a.nhit = i + 11 * Cp; a.slot = i + 12 * Cp;
+    a.gen = reinterpret_cast<uint32_t*>(i + 13 * Cp);
+    a.choose = reinterpret_cast<uint8_t*>(i + 14 * Cp);
     a.Cp = (int)Cp;
     return a;
 }
@@ -142,7 +142,9 @@ __global__ __launch_bounds__(256) void k_nuts_begin(const double* V, const doubl
     nuts_store_partials<CM, 1>(acc, part, pstride, ldp, C);
 }
 
-// first half of a leapfrog step from the edge the chain grows: WR = r + (es / 2) g ; WX = theta + es WR, es = dir * eps
+// first half of a leapfrog step from the edge the chain grows: WR = r + (es / 2) g ; WX = theta + es WR, es = dir * eps.
+// WX (and with it MU, S, the new gradient and the new log density) lives in the chain's PACKED column nc.slot: only
+// the chains whose trees still grow take part in the two products
 template <bool CM>
 __global__ __launch_bounds__(256) void k_nuts_leap_pre(NutsVecs nv, double* WX, double* WR, int ld, int Q, int C, NutsChain nc)
 {
@@ -160,7 +162,8 @@ __global__ __launch_bounds__(256) void k_nuts_leap_pre(NutsVecs nv, double* WX, 
         const double g = d > 0 ? nv.GP[off] : nv.GM[off];
         const double rh = r + (0.5 * es) * g;
         WR[off] = rh;
-        WX[off] = th + es * rh;
+        const int sl = nc.slot[ch];                                // the products run on the packed columns
+        WX[CM ? sl + (size_t)s * ld : f + (size_t)sl * ld] = th + es * rh;
     }
 }
 
@@ -182,7 +185,9 @@ __global__ __launch_bounds__(256) void k_nuts_leap_post(const double* WX, const 
         const size_t off = f + (size_t)s * ld;
         const int d = nc.dir[ch];
         const double es = d * nc.eps[ch];
-        const double g = GN[off], x = WX[off];
+        const int sl = nc.slot[ch];
+        const size_t offc = CM ? sl + (size_t)s * ld : f + (size_t)sl * ld;
+        const double g = GN[offc], x = WX[offc];
         const double rn = WR[off] + (0.5 * es) * g;
         if (d > 0) { nv.TP[off] = x; nv.RP[off] = rn; nv.GP[off] = g; }
         else { nv.TM[off] = x; nv.RM[off] = rn; nv.GM[off] = g; }
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(256) void k_nuts_leaf_fin(const double* part, int n
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const double kin = cm_sum_chunks(part, nchunk, ldp, c < C ? c : 0);
     if (threadIdx.x >= 64 || c >= C || !nc.active[c]) return;
-    double h = -1 * nc.lp_new[c] + 0.5 * kin;
+    double h = -1 * nc.lp_new[nc.slot[c]] + 0.5 * kin;
     if (isnan(h)) h = INFINITY;
     const double H0 = nc.H0[c];
     nc.nleap[c] += 1;
@@ -371,6 +376,20 @@ __global__ void k_nuts_count(const int* flag, int C, int* out)
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// packed column of every growing chain (ascending chain order), -1 for the others; one 256-thread workgroup
+__global__ __launch_bounds__(256) void k_nuts_slots(const int* active, int C, int* slot, int identity)
+{
+    __shared__ int cnt[256];
+    const int per = (C + 255) / 256, c0 = threadIdx.x * per, c1 = (c0 + per < C) ? c0 + per : C;
+    int n = 0;
+    for (int c = c0; c < c1; ++c) n += (identity || active[c]) ? 1 : 0;
+    cnt[threadIdx.x] = n;
+    __syncthreads();
+    int base = 0;
+    for (int t = 0; t < (int)threadIdx.x; ++t) base += cnt[t];
+    for (int c = c0; c < c1; ++c) slot[c] = (identity || active[c]) ? base++ : -1;
 }
 
 // end of a transition: stepsize_adaptation::learn_stepsize / complete_adaptation
@@ -458,11 +477,11 @@ struct NutsRun {
         if (h.cm) {
             const CmParts p = cm_parts(c);
             MCML_TRY(cm_logprob_partials(c, h.UP.d(), nullptr, var_par));
-            hipLaunchKernelGGL(k_cm_lp0_fin, dim3((C + 63) / 64), dim3(256), 0, c.stream, p.ll, p.lp, p.nchn, p.nchq, p.ldp, C,
-                               nc.lp_new);
+            hipLaunchKernelGGL(k_cm_lp0_fin, dim3((h.Cw + 63) / 64), dim3(256), 0, c.stream, p.ll, p.lp, p.nchn, p.nchq, p.ldp,
+                               h.Cw, nc.lp_new);
         } else
-            hipLaunchKernelGGL(k_hmc_lp0, dim3(C), dim3(256), 0, c.stream, h.MU.d(), h.MU.ld, c.n, h.UP.d(), h.UP.ld, Q, c.y.d(),
-                               var_par, c.flink, nc.lp_new);
+            hipLaunchKernelGGL(k_hmc_lp0, dim3(h.Cw), dim3(256), 0, c.stream, h.MU.d(), h.MU.ld, c.n, h.UP.d(), h.UP.ld, Q,
+                               c.y.d(), var_par, c.flink, nc.lp_new);
         MCML_HIP(hipGetLastError());
         return hmc_backward(c, h.UP.d(), h.GRADP.d(), 0, var_par, 0);
     }
@@ -479,8 +498,19 @@ struct NutsRun {
         ++leapfrogs;
         return MCML_OK;
     }
+    // pack the growing chains (nact of them) into the first columns the products process
+    int pack(int nact)
+    {
+        hipLaunchKernelGGL(k_nuts_slots, dim3(1), dim3(256), 0, c.stream, nc.active, C, nc.slot, nact >= C ? 1 : 0);
+        MCML_HIP(hipGetLastError());
+        const int g = h.cm ? 64 : 128;                                 // a wave of chains / a column tile of the GEMMs
+        int cw = round_up(nact, g);
+        h.Cw = cw < C ? cw : C;
+        return MCML_OK;
+    }
     int begin(uint32_t it, uint32_t stream)
     {
+        h.Cw = C;
         MCML_TRY(hmc_eval_state(c, var_par));                          // lpcur, GRAD at V
         ChainArrays ca = chain_arrays(h);
         if (h.cm) vec(k_nuts_begin<true>, h.V.d(), h.GRAD.d(), nv, ld, Q, C, seed, chain_offset, it, stream, part, pstride, ldp);
@@ -501,7 +531,9 @@ struct NutsRun {
     int transition(uint32_t it, int max_depth)
     {
         MCML_TRY(begin(it, 16u * iter_idx + 4u));
+        int nact = C;
         for (int j = 0; j < max_depth; ++j) {
+            MCML_TRY(pack(nact));
             hipLaunchKernelGGL(k_nuts_begin_doubling, dim3((C + 255) / 256), dim3(256), 0, c.stream, C, nc, 0);
             const int nleaf = 1 << j;
             for (int n = 0; n < nleaf; ++n) {
@@ -530,7 +562,9 @@ struct NutsRun {
             int na = 0;
             MCML_TRY(count_active(&na));
             if (na == 0) break;
+            nact = na;
         }
+        h.Cw = C;
         if (h.cm) vec(k_nuts_commit<true>, nv.Tth, h.V.d(), ld, Q, C);
         else vec(k_nuts_commit<false>, nv.Tth, h.V.d(), ld, Q, C);
         MCML_HIP(hipGetLastError());
@@ -541,6 +575,7 @@ struct NutsRun {
     {
         for (int round = 0; round < 80; ++round) {
             MCML_TRY(begin((uint32_t)round, 16u * iter_idx + 5u));
+            MCML_TRY(pack(C));
             hipLaunchKernelGGL(k_nuts_begin_doubling, dim3((C + 255) / 256), dim3(256), 0, c.stream, C, nc, 1);
             MCML_TRY(leaf(0));
             hipLaunchKernelGGL(k_nuts_heur_fin, dim3((C + 255) / 256), dim3(256), 0, c.stream, C, nc, round);

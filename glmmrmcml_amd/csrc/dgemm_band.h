@@ -155,8 +155,18 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
     // epilogue stores -- vector memory completes in order, its `s_waitcnt vmcnt(0)` drains every store before
     // the next item's first LDS-DMA can even be issued: measured 471 vs 428 us per launch at 1024 chains.
     const int it0 = bp.wg_ptr[pw], it1 = bp.wg_ptr[pw + 1];
-    for (int it = it0; it < it1; ++it) {
-        BandItem item;
+    // the item being worked on and its operand addressing; load_item() replaces them (after a K loop they are dead)
+    BandItem item{0, 0, 0, -1};
+    int m0 = 0;
+    unsigned voa[BD_NA]; int la[BD_NA];
+#pragma unroll
+    for (int s = 0; s < BD_NA; ++s) {
+        int c = wave + 8 * s;
+        if (c >= 20) c = wave + 8;                          // waves 4-7 repeat a chunk: uniform vmcnt
+        la[s] = c * 1024;                                   // LDS offset of the piece: the same for every item
+    }
+    const char* sA = nullptr; const char* sB = nullptr;                 // uniform
+    auto load_item = [&](int it) {
 #if defined(__HIP_DEVICE_COMPILE__)
         {
             typedef int i4s __attribute__((ext_vector_type(4)));
@@ -168,11 +178,7 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
 #else
         item = bp.items[it];
 #endif
-        const int band = item.band;
-        const int m0 = band * BD_BM;
-        const int kt0 = item.kt0, kt1 = item.kt1;
-
-        unsigned voa[BD_NA]; int la[BD_NA];
+        m0 = item.band * BD_BM;
 #pragma unroll
         for (int s = 0; s < BD_NA; ++s) {
             int c = wave + 8 * s;
@@ -182,51 +188,57 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
             int gm = m0 + m;
             if (gm >= p.M) gm = 0;
             voa[s] = (unsigned)((gm + (size_t)k * p.lda) * 8);
-            la[s] = c * 1024;
         }
-        const char* sA = reinterpret_cast<const char*>(p.A) + (size_t)kt0 * stepA;          // uniform
-        const char* sB = reinterpret_cast<const char*>(p.B) + (size_t)kt0 * (BD_BK * 8);
-
-        auto issue = [&](int stage) {
+        sA = reinterpret_cast<const char*>(p.A) + (size_t)item.kt0 * stepA;
+        sB = reinterpret_cast<const char*>(p.B) + (size_t)item.kt0 * (BD_BK * 8);
+    };
+    auto issue = [&](int stage) {
 #if defined(__HIP_DEVICE_COMPILE__)
-            // hand-written so that the scalar-base form is what runs (hipcc materialises base + offset into one
-            // 64-bit temporary per load instead); M0 = LDS byte address of the piece, lane l lands at M0 + 16 l;
-            // the s_nop is the wait state an LDS-DMA needs behind a SALU write of M0 (hipcc pads nothing inside asm)
-            const unsigned lbase = (unsigned)(size_t)(lds_ptr_t)lds + stage * BD_STAGE_BYTES;
+        // hand-written so that the scalar-base form is what runs (hipcc materialises base + offset into one
+        // 64-bit temporary per load instead); M0 = LDS byte address of the piece, lane l lands at M0 + 16 l;
+        // the s_nop is the wait state an LDS-DMA needs behind a SALU write of M0 (hipcc pads nothing inside asm)
+        const unsigned lbase = (unsigned)(size_t)(lds_ptr_t)lds + stage * BD_STAGE_BYTES;
 #pragma unroll
-            for (int s = 0; s < BD_NA; ++s)
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                             :: "s"(lbase + la[s]), "v"(voa[s]), "s"(sA) : "memory", "m0");
+        for (int s = 0; s < BD_NA; ++s)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(lbase + la[s]), "v"(voa[s]), "s"(sA) : "memory", "m0");
 #pragma unroll
-            for (int s = 0; s < BD_NB; ++s)
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                             :: "s"(lbase + lb[s]), "v"(vob[s]), "s"(sB) : "memory", "m0");
-            sA += stepA;
-            sB += BD_BK * 8;
+        for (int s = 0; s < BD_NB; ++s)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(lbase + lb[s]), "v"(vob[s]), "s"(sB) : "memory", "m0");
+        sA += stepA;
+        sB += BD_BK * 8;
 #else
-            (void)stage; (void)stepA; (void)sA; (void)sB;
+        (void)stage; (void)stepA; (void)sA; (void)sB;
 #endif
-        };
-        auto wait_leave = [&](int tiles) {
-            static_assert(BD_PER_TILE == 7, "vmcnt immediates below");
-            if (tiles >= 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-            else if (tiles == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
+    };
+    auto wait_leave = [&](int tiles) {
+        static_assert(BD_PER_TILE == 7, "vmcnt immediates below");
+        if (tiles >= 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else if (tiles == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    const int mode = DBG ? bp.mode : 0;
+    // `pre`: the first ring stages of the item about to start are already in flight -- they were issued BEFORE the
+    // previous item's epilogue (the ring is free once every wave has passed the last barrier of a K loop), so the
+    // fill's memory latency runs under the epilogue's loads and stores instead of after them
+    bool pre = false;
+    int issued = 0;
+    if (it0 < it1) load_item(it0);
+    for (int it = it0; it < it1;) {
+        const int band = item.band, e_m0 = m0, slot = item.slot;
+        const int nk = item.kt1 - item.kt0;
 
         d4 acc[5][1];
 #pragma unroll
         for (int i = 0; i < 5; ++i) acc[i][0] = d4{0.0, 0.0, 0.0, 0.0};
 
-        const int nk = kt1 - kt0;
-        const int mode = DBG ? bp.mode : 0;
         if (nk > 0 && mode == 0) {
             // per-lane LDS byte addresses of the operand reads inside stage 0
             const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)lds;
             const unsigned aoff = lds0 + lk * (BD_BM * 8) + l15 * 8;
             const unsigned boff = lds0 + BD_A_BYTES + (((lk >> 1) * BD_BN + wave * 16 + l15) << 4) + ((lk & 1) << 3);
-            int issued = 0;
-            for (; issued < BD_STAGES - 1 && issued < nk; ++issued) issue(issued);
+            if (!pre) { issued = 0; for (; issued < BD_STAGES - 1 && issued < nk; ++issued) issue(issued); }
             wait_leave(issued - 1);
             __builtin_amdgcn_s_barrier();
             int st = 0;
@@ -323,19 +335,30 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
                 st = st + 1; if (st >= BD_STAGES) st = 0;
             }
         }
-        if (item.slot < 0) {
-            epi(acc, m0, n0 + wave * 16, lane, p.M, p.N, band);
+        ++it;
+        pre = false;
+        if (it < it1) {
+            load_item(it);
+            const int nkn = item.kt1 - item.kt0;
+            if (mode == 0 && nk > 0 && nkn > 0) {
+                issued = 0;
+                for (; issued < BD_STAGES - 1 && issued < nkn; ++issued) issue(issued);
+                pre = true;
+            }
+        }
+        if (slot < 0) {
+            epi(acc, e_m0, n0 + wave * 16, lane, p.M, p.N, band);
         } else {
             // raw accumulator tile in register order: element (wave, i, r, lane) -- each store instruction
             // writes 512 contiguous bytes; k_band_reduce reads it back with the same thread mapping
-            double* P = bp.part + ((size_t)item.slot * p.gn + bj) * BD_TILE_ELEMS + (size_t)wave * (20 * 64) + lane;
+            double* P = bp.part + ((size_t)slot * p.gn + bj) * BD_TILE_ELEMS + (size_t)wave * (20 * 64) + lane;
 #pragma unroll
             for (int i = 0; i < 5; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) P[(i * 4 + r) * 64] = acc[i][0][r];
         }
-        // the next item's first LDS-DMA may overwrite a stage another wave is still reading
-        __builtin_amdgcn_s_barrier();
+        // without a prefetch the next item's first LDS-DMA may overwrite a stage another wave is still reading
+        if (!pre) __builtin_amdgcn_s_barrier();
     }
     if constexpr (DBG)
         if (bp.clocks && blockIdx.x == 0 && tid == 0) {

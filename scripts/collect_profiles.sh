@@ -39,6 +39,10 @@ for c in cfg4 cfg5; do
   $PY scripts/make_traffic_json.py $O/f_$c $O/w_$c 0 $C 0 "$BUILD" > $O/${c}_hbm_traffic.json
 done
 echo "cfg4/cfg5 done"
+# 6. the No-U-Turn sampler on the bench workload and on config 4
+$PY scripts/time_nuts.py 5000 1024 20 > $O/nuts_timing.txt 2>&1
+$PY scripts/time_nuts.py cfg4 512 20 >> $O/nuts_timing.txt 2>&1
+echo "nuts done"
 # keep the merge-back small: drop the raw traces
 find $O -name "*_results.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
 ls -la $O

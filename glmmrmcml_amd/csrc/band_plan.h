@@ -29,11 +29,19 @@ struct BandPlanDev {
     DevBuf items, wg_ptr, red, part;
 };
 
+// the few-column products (dgemm_skinny.h): chunk range of every 256-row block, partial sums
+struct SkinnyPlan {
+    int nrb = 0, nkc = 0, ldp = 0;
+    DevBuf range;                 // int2 per row block: first chunk of 128 K columns, one past the last
+    DevBuf part;                  // nkc x 16 x ldp doubles
+};
+
 struct BandPlan {
     int M = 0, K = 0, nbands = 0;
     std::vector<int> kr;                  // host copy of the K-tile ranges, 2 per band
     long tiles = 0;                       // sum over bands of K tiles multiplied
     std::map<int, std::unique_ptr<BandPlanDev>> by_gn;
+    std::unique_ptr<SkinnyPlan> skinny;
 
     void reset(int M_, int K_, const std::vector<int>& kr_)
     {
@@ -41,6 +49,7 @@ struct BandPlan {
         tiles = 0;
         for (int b = 0; b < nbands; ++b) tiles += kr[2 * b + 1] - kr[2 * b];
         by_gn.clear();
+        skinny.reset();
     }
 
     // target_wg: workgroups the launch should have in all (one per CU)

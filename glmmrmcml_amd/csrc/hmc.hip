@@ -19,6 +19,7 @@
 #include "dgemm_mfma.h"
 #include "dgemm_dlds.h"
 #include "dgemm_band.h"
+#include "dgemm_skinny.h"
 #include "glm.h"
 #include "reduce.h"
 #include "rng.h"
@@ -443,11 +444,20 @@ static bool use_dlds()
     return v == 1;
 }
 
+static bool use_skinny()                       // GLMMR_MCML_SKINNY=0: the MFMA kernels whatever the column count
+{                                              // (read per call: the parity tests run both paths in one process)
+    const char* e = getenv("GLMMR_MCML_SKINNY");
+    return !(e && !strcmp(e, "0"));
+}
+
 // MU = xb + ZL * X ; S = score
 template <class Epi>
 static int hmc_forward_launch(Ctx& c, const double* X, int ldx, const Epi& epi)
 {
     HmcState& h = c.hmc;
+    // at most 4 chains (chains = 1: the reference's layout; the tail of a NUTS doubling): an HBM-bound stream, not an MFMA tile
+    if (use_skinny() && skinny_applicable(c.plan_fwd, c.n, c.Q, h.Cw, c.ZL.ld))
+        return launch_skinny(c.stream, c.plan_fwd, h.Cw, c.ZL.d(), c.ZL.ld, X, ldx, epi);
     if (c.band_fwd && dlds_applicable(c.n, h.Cw, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
         return launch_gemm_band(c.stream, c.plan_fwd, h.Cw, c.ZL.d(), c.ZL.ld, X, ldx, epi);
     if (use_dlds() && dlds_applicable(c.n, h.Cw, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
@@ -521,7 +531,9 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
         c.prof.end(c.stream, slot);
         return rc;
     }
-    if (c.band_bwd && dlds_applicable(c.Q, h.Cw, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
+    if (use_skinny() && skinny_applicable(c.plan_bwd, c.Q, c.n, h.Cw, c.ZLT.ld))
+        rc = launch_skinny(c.stream, c.plan_bwd, h.Cw, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
+    else if (c.band_bwd && dlds_applicable(c.Q, h.Cw, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
         rc = launch_gemm_band(c.stream, c.plan_bwd, h.Cw, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
     else if (use_dlds() && dlds_applicable(c.Q, h.Cw, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
         rc = launch_gemm_dlds(c.stream, c.Q, h.Cw, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);

@@ -505,6 +505,7 @@ struct NutsRun {
         MCML_HIP(hipGetLastError());
         const int g = h.cm ? 64 : 128;                                 // a wave of chains / a column tile of the GEMMs
         int cw = round_up(nact, g);
+        if (!h.cm && nact <= SK_NUSE) cw = nact;                       // few enough for the streamed products (dgemm_skinny.h)
         h.Cw = cw < C ? cw : C;
         return MCML_OK;
     }
@@ -548,10 +549,11 @@ struct NutsRun {
                 // push: the node under construction becomes the stored node of level tz (all growing chains agree)
                 std::swap(Srho[tz], nv.Crho); std::swap(Spb[tz], nv.Cpb); std::swap(Sth[tz], nv.Cth);
                 MCML_HIP(hipGetLastError());
-                if ((n & 15) == 15 && n + 1 < nleaf) {                 // deep trees: stop early once every chain has
-                    int na = 0;
-                    MCML_TRY(count_active(&na));
+                if ((n & 15) == 15 && n + 1 < nleaf) {                 // deep doublings: stop once every chain has, and
+                    int na = 0;                                        // re-pack when a quarter of the packed chains
+                    MCML_TRY(count_active(&na));                       // have stopped (nothing packed outlives a leaf)
                     if (na == 0) break;
+                    if (4 * na <= 3 * nact) { MCML_TRY(pack(na)); nact = na; }
                 }
             }
             hipLaunchKernelGGL(k_nuts_end_doubling, dim3((C + 255) / 256), dim3(256), 0, c.stream, C, nc, j);

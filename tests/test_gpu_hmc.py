@@ -46,15 +46,27 @@ CASES = [(synth.geospatial, dict(n=96), 0.9), (synth.geospatial, dict(n=333), 1.
          (synth.stepped_wedge, dict(ncl=6, nt=4, nind=30), 1.0)]
 
 
+@pytest.fixture(params=["skinny", "mfma"])
+def few_chain_path(request, monkeypatch):
+    """at most 4 chains run the streamed products of dgemm_skinny.h unless GLMMR_MCML_SKINNY=0: the few-chain parity
+    tests run with both settings (5 chains / columns take the MFMA kernels either way, 1 chain switches)"""
+    if request.param == "mfma":
+        monkeypatch.setenv("GLMMR_MCML_SKINNY", "0")
+    else:
+        monkeypatch.delenv("GLMMR_MCML_SKINNY", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("gen,kw,vp", CASES)
-def test_log_prob_and_log_grad(orc, gen, kw, vp):
+def test_log_prob_and_log_grad(orc, gen, kw, vp, few_chain_path):
     from glmmrmcml_amd import api
     d = gen(**kw)
     ctx, ZL, xb, fl, _ = _setup(orc, d, api)
     rng = np.random.default_rng(3)
-    V = rng.normal(size=(d["Q"], 5)) * 0.7
+    ncol = 3 if few_chain_path == "skinny" else 5          # <= 4 columns: the streamed products
+    V = rng.normal(size=(d["Q"], ncol)) * 0.7
     lp, G = ctx.log_prob_grad(d["beta"], vp, V)
-    for c in range(5):
+    for c in range(ncol):
         lo = orc.log_prob(xb, ZL, d["y"], vp, fl, V[:, c])
         go = orc.log_grad(xb, ZL, d["y"], vp, fl, V[:, c])
         assert abs(lp[c] - lo) < 1e-11 * abs(lo)
@@ -63,15 +75,17 @@ def test_log_prob_and_log_grad(orc, gen, kw, vp):
 
 
 @pytest.mark.parametrize("gen,kw,vp", CASES[:1] + CASES[2:])
-def test_chains_match_oracle_chain_by_chain(orc, gen, kw, vp):
+def test_chains_match_oracle_chain_by_chain(orc, gen, kw, vp, few_chain_path):
     from glmmrmcml_amd import api
     d = gen(**kw)
     ctx, ZL, xb, fl, Lo = _setup(orc, d, api)
     Cn, warm, nsamp, lam, ms, ta, seed, it = 5, 14, 15, 0.4, 6, 0.9, 20240601, 2
+    if few_chain_path == "skinny":
+        Cn = 3                                                 # <= 4 chains: the streamed products
     diag, flags, probs = ctx.hmc_sample(d["beta"], vp, warm, nsamp, lam, ms, ta, seed, chains=Cn,
                                         chain_offset=10, iter_idx=it, adapt=10, want_trace=True)
     u = ctx.get_u()
-    dpc = 3                         # ceil(15 / 5) draws per chain
+    dpc = -(-nsamp // Cn)           # draws per chain
     assert u.shape == (d["Q"], Cn * dpc)
     acc_total = 0
     for c in range(Cn):
@@ -86,7 +100,7 @@ def test_chains_match_oracle_chain_by_chain(orc, gen, kw, vp):
     ctx.close()
 
 
-def test_single_chain_reference_layout_and_injection(orc):
+def test_single_chain_reference_layout_and_injection(orc, few_chain_path):
     """chains=1 reproduces the reference's Q x (nsamp+1) output (mhmcmc.h:126,142,155) and the
     niter quirk (D5); injected initial state / momenta give the same chain as the generated ones"""
     from glmmrmcml_amd import api

@@ -131,6 +131,12 @@ class Context:
         buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
         _lib.check(_lib.lib().glmmr_mcml_ctx_comm_init_rccl(self._h, buf, int(rank), int(world)))
 
+    def comm_allreduce(self, vals):
+        """sum over the ranks through the path the statistics take (self-test of the exchange)"""
+        v = np.ascontiguousarray(vals, dtype=np.float64).copy()
+        _lib.check(_lib.lib().glmmr_mcml_ctx_comm_allreduce(self._h, _p(v), v.size))
+        return v
+
     def comm_stats(self):
         calls = C.c_longlong(); dbl = C.c_longlong(); nat = C.c_int()
         _lib.check(_lib.lib().glmmr_mcml_ctx_comm_stats(self._h, C.byref(calls), C.byref(dbl), C.byref(nat)))

@@ -127,6 +127,13 @@ extern "C" int glmmr_mcml_ctx_comm_init_rccl(glmmr_mcml_ctx* h, const unsigned c
     return MCML_OK;
 }
 
+extern "C" int glmmr_mcml_ctx_comm_allreduce(glmmr_mcml_ctx* h, double* vals, int n)
+{
+    MCML_REQUIRE(h && vals && n > 0 && n <= 4096, "comm_allreduce: bad argument");
+    MCML_HIP(hipSetDevice(h->c.device));
+    return allreduce_host(h->c, vals, n);
+}
+
 extern "C" int glmmr_mcml_ctx_comm_stats(glmmr_mcml_ctx* h, long long* calls, long long* doubles, int* native)
 {
     MCML_REQUIRE(h, "comm_stats: null context");

@@ -84,3 +84,16 @@ def init_native_rccl(ctx, rank, world, group=None, device=None):
     t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
     dist.broadcast(t, src=0, group=group)
     ctx.comm_init_rccl(bytes(t.cpu().tolist()), rank, world)
+    # self-test of the new communicator on known values before anything depends on it; the verdict is shared
+    good = 1
+    try:
+        got = ctx.comm_allreduce([rank + 1.0, 1.0, 0.5 * (rank + 1.0)])
+        tri = world * (world + 1) / 2.0
+        if not (got[0] == tri and got[1] == float(world) and got[2] == 0.5 * tri):
+            good, err = 0, RuntimeError("native all-reduce returned %r on rank %d of %d" % (got.tolist(), rank, world))
+    except Exception as e:                  # noqa: BLE001
+        good, err = 0, e
+    flag = torch.tensor([good], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) != 1:
+        raise RuntimeError("native RCCL all-reduce failed its self-test" + ("" if good else ": %r" % (err,)))

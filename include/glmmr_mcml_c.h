@@ -81,6 +81,11 @@ int glmmr_mcml_ctx_destroy(glmmr_mcml_ctx* ctx);
 #define GLMMR_MCML_RCCL_ID_BYTES 128
 int glmmr_mcml_rccl_unique_id(unsigned char* id128);
 int glmmr_mcml_ctx_comm_init_rccl(glmmr_mcml_ctx* ctx, const unsigned char* id128, int rank, int world);
+/* Sums vals[0..n) over the ranks of the context's group through the very path the statistics take (native RCCL
+ * communicator or reduce hook; identity for a single process) and returns the sums in place: a caller's self-test
+ * of the exchange before it commits to it (glmmrmcml_amd/dist.py::init_native_rccl). */
+int glmmr_mcml_ctx_comm_allreduce(glmmr_mcml_ctx* ctx, double* vals, int n);
+
 /* collectives issued so far, doubles summed, 1 if the native communicator is in use (all nullable) */
 int glmmr_mcml_ctx_comm_stats(glmmr_mcml_ctx* ctx, long long* calls, long long* doubles, int* native);
 

@@ -84,3 +84,25 @@ def test_gen_u_samples_export(orc):
     assert got.shape == (d["Q"], 16) and np.isfinite(got).all()
     assert np.abs(got - want).max() < 1e-9
     assert np.abs(got).max() > 0
+
+
+def test_sharded_chains_equal_unsharded_chains():
+    """a chain's draws depend on its GLOBAL id only (momenta, initial state and the uniform stream are keyed by it):
+    ranks that own chains [0, 2) and [2, 4) reproduce the 4-chain run column for column -- and the packing of the
+    chains that still grow (csrc/nuts.h) does not depend on who else is in the batch"""
+    from glmmrmcml_amd import api
+    d = synth.geospatial(60, seed=8)
+    out = {}
+    with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"]) as ctx:
+        ctx.update_L(d["theta"])
+        for name, (C, off) in dict(all=(4, 0), lo=(2, 0), hi=(2, 2)).items():
+            dg, tr = ctx.nuts_sample(d["beta"], d["sigma"], 12, 2 * C, seed=31, chains=C, chain_offset=off, iter_idx=1,
+                                     max_treedepth=7, want_trace=True)
+            out[name] = (ctx.get_u(), tr)
+    u, tr = out["all"]
+    assert np.array_equal(tr["depth"][:2], out["lo"][1]["depth"]) and np.array_equal(tr["depth"][2:], out["hi"][1]["depth"])
+    assert np.array_equal(tr["nleap"][:2], out["lo"][1]["nleap"]) and np.array_equal(tr["nleap"][2:], out["hi"][1]["nleap"])
+    # 2 draws per chain, chain-major columns; the products of a 2-chain run are the streamed kernels, of the 4-chain
+    # run the MFMA tiles: equal to rounding, not bit for bit
+    assert np.abs(u[:, :4] - out["lo"][0]).max() < 1e-8 * max(1.0, np.abs(u).max())
+    assert np.abs(u[:, 4:] - out["hi"][0]).max() < 1e-8 * max(1.0, np.abs(u).max())

@@ -142,6 +142,8 @@ def test_native_rccl_single_rank_group():
         ub = ctx.get_u()
     with api.Context(*args) as ctx:
         ctx.comm_init_rccl(api.rccl_unique_id(), 0, 1)
+        # the self-test dist.init_native_rccl runs before it commits to the native path (1 rank: the identity)
+        assert np.array_equal(ctx.comm_allreduce([1.0, 1.0, 0.5]), [1.0, 1.0, 0.5])
         got = ctx.mcml_full(d["start"], **kw)
         ug = ctx.get_u()
         st = ctx.comm_stats()

@@ -21,5 +21,13 @@ r = ctx.mcml_full(d["start"], mcnr=True, m=64, maxiter=2, warmup=20, tol=0.0, ve
 print("beta", r["beta"], "theta", r["theta"], "iters", r["iters"])
 print("reduce hook calls:", len(calls), "payload sizes:", sorted(set(calls)))
 ctx.close()
+# the native path of bench.py on the same 1-rank group: the id travels through torch.distributed, the library makes its
+# own communicator, the all-reduce is self-tested on known values (dist.init_native_rccl), then a fit runs through it
+ctx = api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"], device=0)
+gdist.init_native_rccl(ctx, 0, 1)
+r2 = ctx.mcml_full(d["start"], mcnr=True, m=64, maxiter=2, warmup=20, tol=0.0, verbose=False, lambda_=2.0, maxsteps=5,
+                   seed=11, chains=64, maxfun=15)
+print("native:", ctx.comm_stats(), "beta", r2["beta"], "theta", r2["theta"])
+ctx.close()
 tdist.destroy_process_group()
 print("nccl rehearsal ok")

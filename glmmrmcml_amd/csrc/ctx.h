@@ -162,8 +162,15 @@ struct Ctx {
     // side stream + events for the Cholesky look-ahead (mvn.hip potrf_blocked)
     hipStream_t aux = nullptr;
     hipEvent_t ev_col = nullptr, ev_leaf = nullptr;
+    // the factorisation's launch sequence as a hipGraph (mvn.hip potrf_graphed): the theta-step evaluates the same
+    // (matrix, shape) dozens of times per MCML iteration; key = what the captured kernels' arguments depend on
+    struct CholGraph {
+        hipGraphExec_t exec = nullptr;
+        const double* A = nullptr; const double* linv = nullptr; int lda = 0, n = 0, extra = 0, seen = 0;
+    } chol_graph;
     ~Ctx() {
         comm_release_hook();
+        if (chol_graph.exec) (void)hipGraphExecDestroy(chol_graph.exec);
         if (ev_col) (void)hipEventDestroy(ev_col);
         if (ev_leaf) (void)hipEventDestroy(ev_leaf);
         if (aux) (void)hipStreamDestroy(aux);

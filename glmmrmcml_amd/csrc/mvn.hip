@@ -721,6 +721,52 @@ static int potrf_blocked(Ctx& c, double* A, int lda, int n, int extra)
     return MCML_OK;
 }
 
+// The same factorisation replayed as a hipGraph.  A theta-step evaluates one (matrix, shape) 40 times per MCML
+// iteration and every evaluation is ~200 launches, ~80 event operations and the host calls behind them: the first
+// call with a given key runs eagerly (function attributes, allocations), the second is captured (fork / join of the
+// look-ahead included: the side stream joins the capture through its event waits), later ones are one hipGraphLaunch.
+// GLMMR_MCML_CHOL_GRAPH=0 keeps the eager launches.
+static bool chol_graph_on()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GLMMR_MCML_CHOL_GRAPH"); v = (e && !strcmp(e, "0")) ? 0 : 1; }
+    return v == 1;
+}
+static int potrf_graphed(Ctx& c, double* A, int lda, int n, int extra)
+{
+    if (!chol_graph_on() || !(chol_mode() == 1 && n > 2 * CHOL_NB)) return potrf_blocked(c, A, lda, n, extra);
+    Ctx::CholGraph& g = c.chol_graph;
+    const bool same = g.A == A && g.linv == c.linv.d() && g.lda == lda && g.n == n && g.extra == extra;
+    if (same && g.exec) { MCML_HIP(hipGraphLaunch(g.exec, c.stream)); return MCML_OK; }
+    if (!same) {
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+        g.A = A; g.linv = c.linv.d(); g.lda = lda; g.n = n; g.extra = extra; g.seen = 0;
+    }
+    if (g.seen++ <= 0) return potrf_blocked(c, A, lda, n, extra);          // eager first: attributes, allocations
+    MCML_TRY(lookahead_setup(c));
+    if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();                                           // e.g. the legacy default stream: eager for good
+        g.seen = -(1 << 30);
+        return potrf_blocked(c, A, lda, n, extra);
+    }
+    const int rc = potrf_blocked(c, A, lda, n, extra);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(c.stream, &graph);
+    if (rc != MCML_OK || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        g.seen = 0; g.A = nullptr;                                         // fall back to eager launches for good
+        if (rc != MCML_OK) return rc;
+        set_error("potrf: stream capture failed: %s", hipGetErrorString(e));
+        return MCML_EHIP;
+    }
+    const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { g.exec = nullptr; set_error("potrf: hipGraphInstantiate: %s", hipGetErrorString(ei)); return MCML_EHIP; }
+    MCML_HIP(hipGraphLaunch(g.exec, c.stream));
+    return MCML_OK;
+}
+
 static int trsm_left_blocked(Ctx& c, const double* L, int ldl, int n, double* U, int ldu, int m)
 {
     for (int k = 0; k < n; k += CHOL_NB) {
@@ -925,7 +971,7 @@ int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out)
                 MCML_TRY(c.linv.ensure(sizeof(double) * (size_t)(dp / CHOL_NB + 1) * CHOL_NB * CHOL_NB));
                 MCML_HIP(hipMemsetAsync(c.linv.p, 0, sizeof(double) * (size_t)((dp + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB, c.stream));
                 MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_potrf_leaf), (int)POTRF_LDS));
-                MCML_TRY(potrf_blocked(c, c.Dwork.d(), c.Dwork.ld, dp, m));
+                MCML_TRY(potrf_graphed(c, c.Dwork.d(), c.Dwork.ld, dp, m));
                 Z = c.Dwork.d() + dp; ldz = c.Dwork.ld; zr = m; zc = d;
             } else {
                 MCML_TRY(potrf_lower(c, c.Dwork.d(), d, c.Dwork.ld));

@@ -148,3 +148,28 @@ def test_longitudinal_poisson_reduced(orc):
     H = api.mcml_hess(*args, u, d["family"], d["link"], np.r_[want["beta"], want["theta"], 1.0], tol=1e-4)
     Ho = drivers.mcml_hess(mod, u, np.r_[want["beta"], want["theta"], 1.0], tol=1e-4)
     assert np.abs(H - Ho).max() < 1e-4 * np.abs(Ho).max()
+
+
+@pytest.mark.parametrize("chains", [1, 4])
+def test_streamed_and_mfma_products_agree_at_full_size(monkeypatch, chains):
+    """n = Q = 5000, <= 4 chains: the streamed products (dgemm_skinny.h: 20 row blocks, 40 K chunks, the zero K ranges
+    of the triangular ZL never launched into) against the 128-column MFMA tiles on the same chains -- identical
+    accept/reject decisions, samples to rounding (chains = 1 is the reference's layout, Q x (m + 1))"""
+    from glmmrmcml_amd import api
+    d = synth.geospatial(5000)
+    out = {}
+    with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"]) as ctx:
+        ctx.update_L(d["theta"])
+        for mode in ("skinny", "mfma"):
+            if mode == "mfma":
+                monkeypatch.setenv("GLMMR_MCML_SKINNY", "0")
+            else:
+                monkeypatch.delenv("GLMMR_MCML_SKINNY", raising=False)
+            diag, flags, probs = ctx.hmc_sample(d["beta"], d["sigma"], 12, 4 * chains, 5.0, 10, 0.9, seed=9, chains=chains,
+                                                want_trace=True)
+            out[mode] = (ctx.get_u(), flags.copy(), probs.copy())
+    monkeypatch.delenv("GLMMR_MCML_SKINNY", raising=False)
+    assert out["skinny"][0].shape == (5000, 5 if chains == 1 else 16)
+    assert np.array_equal(out["skinny"][1], out["mfma"][1])
+    assert np.abs(out["skinny"][2] - out["mfma"][2]).max() < 1e-9
+    assert np.abs(out["skinny"][0] - out["mfma"][0]).max() < 1e-8 * np.abs(out["mfma"][0]).max()

@@ -160,8 +160,9 @@ struct Ctx {
     DevBuf scratch;             // short-lived per-call scratch
 
     // side stream + events for the Cholesky look-ahead (mvn.hip potrf_blocked)
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_col = nullptr, ev_leaf = nullptr;
+    hipStream_t aux = nullptr;      // high priority: the leaf of the eager fork-join
+    hipStream_t aux_lo = nullptr;   // lowest priority: the bulk chain of the captured schedule
+    hipEvent_t ev_col = nullptr, ev_leaf = nullptr, ev_ps = nullptr, ev_b = nullptr;
     // the factorisation's launch sequence as a hipGraph (mvn.hip potrf_graphed): the theta-step evaluates the same
     // (matrix, shape) dozens of times per MCML iteration; key = what the captured kernels' arguments depend on
     struct CholGraph {
@@ -173,7 +174,10 @@ struct Ctx {
         if (chol_graph.exec) (void)hipGraphExecDestroy(chol_graph.exec);
         if (ev_col) (void)hipEventDestroy(ev_col);
         if (ev_leaf) (void)hipEventDestroy(ev_leaf);
+        if (ev_ps) (void)hipEventDestroy(ev_ps);
+        if (ev_b) (void)hipEventDestroy(ev_b);
         if (aux) (void)hipStreamDestroy(aux);
+        if (aux_lo) (void)hipStreamDestroy(aux_lo);
     }
 
     int sync() { MCML_HIP(hipStreamSynchronize(stream)); return MCML_OK; }

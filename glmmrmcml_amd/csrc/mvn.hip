@@ -643,8 +643,11 @@ static int lookahead_setup(Ctx& c)
     int lo = 0, hi = 0;
     MCML_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     MCML_HIP(hipStreamCreateWithPriority(&c.aux, hipStreamNonBlocking, hi));
+    MCML_HIP(hipStreamCreateWithPriority(&c.aux_lo, hipStreamNonBlocking, lo));
     MCML_HIP(hipEventCreateWithFlags(&c.ev_col, hipEventDisableTiming));
     MCML_HIP(hipEventCreateWithFlags(&c.ev_leaf, hipEventDisableTiming));
+    MCML_HIP(hipEventCreateWithFlags(&c.ev_ps, hipEventDisableTiming));
+    MCML_HIP(hipEventCreateWithFlags(&c.ev_b, hipEventDisableTiming));
     return MCML_OK;
 }
 
@@ -721,17 +724,106 @@ static int potrf_blocked(Ctx& c, double* A, int lda, int n, int extra)
     return MCML_OK;
 }
 
+// The dependency structure the GRAPH is captured with (never launched eagerly: with cross waits in both directions
+// between two live streams the process deadlocked intermittently, see above; a captured graph has no stream waits).
+// Two chains that only meet through events:
+//   critical (capture stream):  P_small(t)  the 128 x 128 panel block under the diagonal block, X <- X inv(L_t)'
+//                               U_small(t)  D_{t+1} -= X X'
+//                               leaf(t+1)
+//   bulk (side stream):         a(t)  the rest of panel t                       (needs leaf(t))
+//                               b(t)  column blocks t+1 AND t+2, rows below block t+1, -= panel t   (needs P_small(t))
+//                               c(t)  column blocks t+3.., lower tiles only, -= panel t
+// P_small(t+1) / U_small(t+1) touch block (t+2, t+1) and D_{t+2}: both were brought up to date by b(t), so the
+// critical chain waits for b(t) only -- never for the big update c(t) -- and its three kernels sit back to back on one
+// queue; the bulk chain is self-contained (its two waits are satisfied early because the critical chain runs ahead).
+// Every tile still receives its updates in panel order from kernels that accumulate k = 0..127 in order: the factor
+// is bit-identical to potrf_blocked's.
+static int potrf_la2_capture(Ctx& c, double* A, int lda, int n, int extra)
+{
+    int* errflag = c.scalars.as<int>() + 32;
+    hipStream_t sC = c.stream, sB = c.aux_lo;
+    auto leaf = [&](int k, int nb) -> int {
+        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(LEAF_NT), POTRF_LDS, sC, A + k + (size_t)k * lda, lda, nb,
+                           c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB, errflag, nullptr);
+        MCML_HIP(hipGetLastError());
+        return MCML_OK;
+    };
+    auto gemm_nt = [&](hipStream_t st, int M, int N, int K, const double* Ap, const double* Bp, int ldb, double* Cp,
+                       double alpha, double beta, bool lower, int tile, int inplace) -> int {
+        EpiAxpby epi{Cp, lda, alpha, beta};
+        if (dl_applicable(M, N, K, Ap, lda, Bp, ldb, true))
+            return launch_gemm_dl<true>(st, M, N, K, Ap, lda, Bp, ldb, epi, lower, tile, inplace, 0);
+        return launch_gemm<true>(st, M, N, K, Ap, lda, Bp, ldb, epi, lower, inplace ? inplace : -1);
+    };
+    const int nsteps = (n + CHOL_NB - 1) / CHOL_NB;
+    MCML_TRY(leaf(0, n < CHOL_NB ? n : CHOL_NB));
+    MCML_HIP(hipEventRecord(c.ev_leaf, sC));
+    MCML_HIP(hipStreamWaitEvent(sB, c.ev_leaf, 0));                  // the side stream joins the capture; a(0) needs leaf(0)
+    bool have_b = false;
+    for (int t = 0; t < nsteps; ++t) {
+        const int k = t * CHOL_NB;
+        const int nb = (n - k < CHOL_NB) ? n - k : CHOL_NB;
+        double* A11 = A + k + (size_t)k * lda;
+        const double* Linv = c.linv.d() + (size_t)t * CHOL_NB * CHOL_NB;
+        const int rem = n - k - nb, R = rem + extra;
+        if (R <= 0) break;
+        double* A21 = A11 + nb;
+        const int nb2 = rem < CHOL_NB ? rem : CHOL_NB;
+        const int nb3 = (rem - nb2 < CHOL_NB) ? rem - nb2 : CHOL_NB;
+        const int w = nb2 + nb3;                                      // columns b(t) covers
+        // ---- critical chain
+        if (nb2 > 0) {
+            if (have_b) MCML_HIP(hipStreamWaitEvent(sC, c.ev_b, 0));  // b(t-1)
+            MCML_TRY(gemm_nt(sC, nb2, nb, nb, A21, Linv, CHOL_NB, A21, 1.0, 0.0, false, 7, 1));
+            double* T = A11 + nb + (size_t)nb * lda;
+            MCML_TRY(gemm_nt(sC, nb2, nb2, nb, A21, A21, lda, T, -1.0, 1.0, false, 8, 0));
+            MCML_HIP(hipEventRecord(c.ev_ps, sC));
+            MCML_TRY(leaf(k + nb, nb2));
+            MCML_HIP(hipEventRecord(c.ev_leaf, sC));
+        }
+        // ---- bulk chain
+        const int Rb = R - nb2;
+        if (Rb > 0) {
+            MCML_TRY(gemm_nt(sB, Rb, nb, nb, A21 + nb2, Linv, CHOL_NB, A21 + nb2, 1.0, 0.0, false, 0, 1));
+            if (nb2 > 0) {
+                MCML_HIP(hipStreamWaitEvent(sB, c.ev_ps, 0));
+                double* Cb = A11 + nb + nb2 + (size_t)nb * lda;       // rows below block t+1, columns of blocks t+1, t+2
+                MCML_TRY(gemm_nt(sB, Rb, w, nb, A21 + nb2, A21, lda, Cb, -1.0, 1.0, false, 0, 0));
+                MCML_HIP(hipEventRecord(c.ev_b, sB));
+                have_b = true;
+                if (rem - w > 0) {
+                    double* Cc = A11 + nb + w + (size_t)(nb + w) * lda;
+                    MCML_TRY(gemm_nt(sB, R - w, rem - w, nb, A21 + w, A21 + w, lda, Cc, -1.0, 1.0, true, 0, 0));
+                }
+            }
+        } else if (nb2 > 0) {
+            MCML_HIP(hipStreamWaitEvent(sB, c.ev_ps, 0));             // keep the side stream a descendant of every node
+            MCML_HIP(hipEventRecord(c.ev_b, sB));
+            have_b = true;
+        }
+        if (nb2 > 0) MCML_HIP(hipStreamWaitEvent(sB, c.ev_leaf, 0));  // a(t+1) needs leaf(t+1)
+    }
+    MCML_HIP(hipEventRecord(c.ev_b, sB));                             // join
+    MCML_HIP(hipStreamWaitEvent(sC, c.ev_b, 0));
+    return MCML_OK;
+}
+
 // The same factorisation replayed as a hipGraph.  A theta-step evaluates one (matrix, shape) 40 times per MCML
 // iteration and every evaluation is ~200 launches, ~80 event operations and the host calls behind them: the first
 // call with a given key runs eagerly (function attributes, allocations), the second is captured (fork / join of the
 // look-ahead included: the side stream joins the capture through its event waits), later ones are one hipGraphLaunch.
 // GLMMR_MCML_CHOL_GRAPH=0 keeps the eager launches.
-static bool chol_graph_on()
+// GLMMR_MCML_CHOL_GRAPH: 0 eager launches; old = the graph of potrf_blocked's own fork-join; default = potrf_la2_capture
+static int chol_graph_kind()
 {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("GLMMR_MCML_CHOL_GRAPH"); v = (e && !strcmp(e, "0")) ? 0 : 1; }
-    return v == 1;
+    if (v < 0) {
+        const char* e = getenv("GLMMR_MCML_CHOL_GRAPH");
+        v = (e && !strcmp(e, "0")) ? 0 : (e && !strcmp(e, "old")) ? 1 : 2;
+    }
+    return v;
 }
+static bool chol_graph_on() { return chol_graph_kind() != 0; }
 static int potrf_graphed(Ctx& c, double* A, int lda, int n, int extra)
 {
     if (!chol_graph_on() || !(chol_mode() == 1 && n > 2 * CHOL_NB)) return potrf_blocked(c, A, lda, n, extra);
@@ -749,7 +841,7 @@ static int potrf_graphed(Ctx& c, double* A, int lda, int n, int extra)
         g.seen = -(1 << 30);
         return potrf_blocked(c, A, lda, n, extra);
     }
-    const int rc = potrf_blocked(c, A, lda, n, extra);
+    const int rc = chol_graph_kind() == 2 ? potrf_la2_capture(c, A, lda, n, extra) : potrf_blocked(c, A, lda, n, extra);
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(c.stream, &graph);
     if (rc != MCML_OK || e != hipSuccess || !graph) {

@@ -43,6 +43,10 @@ echo "cfg4/cfg5 done"
 $PY scripts/time_nuts.py 5000 1024 20 > $O/nuts_timing.txt 2>&1
 $PY scripts/time_nuts.py cfg4 512 20 >> $O/nuts_timing.txt 2>&1
 echo "nuts done"
+$PY scripts/time_fewchains.py 5000 > $O/fewchains_timing.txt 2>&1
+for g in 2 old 0; do for m in 1024 128; do GLMMR_MCML_CHOL_GRAPH=$g $PY scripts/time_mvn.py 5000 $m 12 2>/dev/null | sed "s/^/CHOL_GRAPH=$g  /" >> $O/mvn_graph_ab.txt; done; done
+$PY scripts/rocpd_timeline.py $O/kt_mvn/m_results.db 260 > $O/mvn_timeline.txt 2>&1
+echo "few chains / graph A-B / timeline done"
 # keep the merge-back small: drop the raw traces
 find $O -name "*_results.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
 ls -la $O

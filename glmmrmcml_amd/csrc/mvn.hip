@@ -160,14 +160,20 @@ __global__ __launch_bounds__(256) void k_build_dense(double* A, int lda, int bid
                                                      const int32_t* cov, int rows, const double* data,
                                                      ThetaArg th, int mirror, int dpad)
 {
-    if (blockIdx.x < blockIdx.y) return;
+    // a workgroup = 64 rows x 16 columns, a wave = the 64 rows of four columns: every store is 512 contiguous bytes
+    // (16 x 16 tiles with 128-byte row groups ran 71 us for the 5000 x 5000 lower triangle)
+    if ((int)blockIdx.x * 64 + 63 < (int)blockIdx.y * 16) return;     // strictly above the diagonal
     const CovBlock blk = blocks[bidx];
-    const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (i >= blk.dim && i < dpad && j <= i) { A[i + (size_t)j * lda] = (i == j) ? 1.0 : 0.0; return; }
-    if (i >= blk.dim || j >= blk.dim || i < j) return;
-    double v = cov_entry(blk, cov, rows, data + blk.doff, th, i, j);
-    A[i + (size_t)j * lda] = v;
-    if (mirror && i != j) A[j + (size_t)i * lda] = v;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = blockIdx.y * 16 + (threadIdx.x >> 6) * 4 + u;
+        if (i >= blk.dim && i < dpad && j <= i) { A[i + (size_t)j * lda] = (i == j) ? 1.0 : 0.0; continue; }
+        if (i >= blk.dim || j >= blk.dim || i < j) continue;
+        const double v = cov_entry(blk, cov, rows, data + blk.doff, th, i, j);
+        A[i + (size_t)j * lda] = v;
+        if (mirror && i != j) A[j + (size_t)i * lda] = v;
+    }
 }
 
 // broadcast lane `src` (compile-time constant) of a double: two v_readlane_b32, no LDS round trip
@@ -845,16 +851,19 @@ static int potrf_graphed(Ctx& c, double* A, int lda, int n, int extra)
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(c.stream, &graph);
     if (rc != MCML_OK || e != hipSuccess || !graph) {
+        // whatever went wrong while recording (nothing has run): eager launches from now on, the error if that fails too
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        g.seen = 0; g.A = nullptr;                                         // fall back to eager launches for good
-        if (rc != MCML_OK) return rc;
-        set_error("potrf: stream capture failed: %s", hipGetErrorString(e));
-        return MCML_EHIP;
+        g.seen = -(1 << 30);
+        return potrf_blocked(c, A, lda, n, extra);
     }
     const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (ei != hipSuccess) { g.exec = nullptr; set_error("potrf: hipGraphInstantiate: %s", hipGetErrorString(ei)); return MCML_EHIP; }
+    if (ei != hipSuccess) {
+        (void)hipGetLastError();
+        g.exec = nullptr; g.seen = -(1 << 30);
+        return potrf_blocked(c, A, lda, n, extra);
+    }
     MCML_HIP(hipGraphLaunch(g.exec, c.stream));
     return MCML_OK;
 }
@@ -1049,7 +1058,7 @@ int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out)
             const int d = blk.dim;
             dim3 g((d + 15) / 16, (d + 15) / 16);
             const int dp = aug ? round_up(d, 2) : d;      // even: the extra rows and every panel stay 16-byte aligned
-            g = dim3((dp + 15) / 16, (dp + 15) / 16);
+            g = dim3((dp + 63) / 64, (dp + 15) / 16);
             hipLaunchKernelGGL(k_build_dense, g, dim3(256), 0, c.stream, c.Dwork.d(), c.Dwork.ld, b, dblk, dcov,
                                cs.rows, c.d_data.d(), th, 0, dp);
             MCML_HIP(hipGetLastError());
@@ -1120,7 +1129,7 @@ int mvn_gen_L(Ctx& c, const double* theta, bool chol)
         if (blk.all_gr) continue;
         const int d = blk.dim;
         double* A = c.L.at(blk.matstart, blk.matstart);
-        dim3 g((d + 15) / 16, (d + 15) / 16);
+        dim3 g((d + 63) / 64, (d + 15) / 16);
         hipLaunchKernelGGL(k_build_dense, g, dim3(256), 0, c.stream, A, c.L.ld, b, dblk, dcov, cs.rows,
                            c.d_data.d(), th, chol ? 0 : 1, d);
         MCML_HIP(hipGetLastError());

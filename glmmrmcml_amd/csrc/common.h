@@ -55,6 +55,18 @@ const char* last_error();
 // (kernel, device) -- a process may hold contexts on several GPUs
 int ensure_dynamic_lds(const void* kernel, int bytes);
 
+// launch KERNEL<FL>: the common families get their own instantiation (1 poisson/log, 3 binomial/logit, 7 gaussian/identity)
+#define MCML_FL_DISPATCH(FLINK, KERNEL, ...)                                          \
+    do {                                                                              \
+        switch (FLINK) {                                                              \
+        case 1: hipLaunchKernelGGL((KERNEL<1>), __VA_ARGS__); break;                  \
+        case 3: hipLaunchKernelGGL((KERNEL<3>), __VA_ARGS__); break;                  \
+        case 7: hipLaunchKernelGGL((KERNEL<7>), __VA_ARGS__); break;                  \
+        default: hipLaunchKernelGGL((KERNEL<0>), __VA_ARGS__); break;                 \
+        }                                                                             \
+    } while (0)
+
+
 static inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
 static inline size_t round_up_sz(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -238,10 +238,14 @@ __global__ __launch_bounds__(256) void k_hmc_init(double* V, int ld, int Q, Chai
 }
 
 // log_prob of column c: sum_i logf(y_i | MU_ic) + sum_k logN(x_k; 0, 1)   (mcmlmodel.h:138-153)
+// FL != 0: the family / link is a compile-time constant -- the 12-way switch of glm_logpdf with its lgamma / tgamma / erfc
+// bodies inlined costs 302 VGPRs (one wave per SIMD) in every kernel that calls it with a run-time code
+template <int FL>
 __device__ __forceinline__ double chain_log_prob(const double* MU, int ldm, int n, const double* X, int ldx,
-                                                 int Q, const double* y, double var_par, int flink, int c,
+                                                 int Q, const double* y, double var_par, int flink_rt, int c,
                                                  double* sh)
 {
+    const int flink = FL ? FL : flink_rt;
     // loads batched four deep (the kernel is latency-bound: 4 workgroups per CU); each thread still adds its
     // own elements in index order, so the sums are bit-identical to the plain loop
     double ll = 0, lp = 0;
@@ -270,11 +274,12 @@ __device__ __forceinline__ double chain_log_prob(const double* MU, int ldm, int 
     return a + b;    // valid in thread 0
 }
 
+template <int FL>
 __global__ __launch_bounds__(256) void k_hmc_lp0(const double* MU, int ldm, int n, const double* V, int ld, int Q,
                                                  const double* y, double var_par, int flink, double* lpcur)
 {
     __shared__ double sh[4];
-    double v = chain_log_prob(MU, ldm, n, V, ld, Q, y, var_par, flink, blockIdx.x, sh);
+    double v = chain_log_prob<FL>(MU, ldm, n, V, ld, Q, y, var_par, flink, blockIdx.x, sh);
     if (threadIdx.x == 0) lpcur[blockIdx.x] = v;
 }
 
@@ -322,6 +327,7 @@ __global__ void k_max_steps(const int* steps, int C, int* out)
 }
 
 // new_proposal, second part (mhmcmc.h:80-117)
+template <int FL>
 __global__ __launch_bounds__(256) void k_hmc_accept(double* V, double* GRAD, const double* R, const double* UP,
                                                     const double* GRADP, int ld, int Q, const double* MU, int ldm,
                                                     int n, const double* y, double var_par, int flink,
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(256) void k_hmc_accept(double* V, double* GRAD, con
     __shared__ double sh[4];
     __shared__ int acc_s;
     const int c = blockIdx.x;
-    double l2 = chain_log_prob(MU, ldm, n, UP, ld, Q, y, var_par, flink, c, sh);
+    double l2 = chain_log_prob<FL>(MU, ldm, n, UP, ld, Q, y, var_par, flink, c, sh);
     double kin = 0;
     for (int k0 = threadIdx.x; k0 < Q; k0 += 1024) {
         double r4[4];
@@ -589,7 +595,7 @@ static int hmc_eval_state(Ctx& c, double var_par)
         hipLaunchKernelGGL(k_cm_lp0_fin, dim3((h.C + 63) / 64), dim3(256), 0, c.stream, p.ll, p.lp, p.nchn, p.nchq, p.ldp,
                            h.C, ca.lpcur);
     } else
-    hipLaunchKernelGGL(k_hmc_lp0, dim3(h.C), dim3(256), 0, c.stream, h.MU.d(), h.MU.ld, c.n, h.V.d(), h.V.ld, c.Q,
+    MCML_FL_DISPATCH(c.flink, k_hmc_lp0, dim3(h.C), dim3(256), 0, c.stream, h.MU.d(), h.MU.ld, c.n, h.V.d(), h.V.ld, c.Q,
                        c.y.d(), var_par, c.flink, ca.lpcur);
     MCML_HIP(hipGetLastError());
     return hmc_backward(c, h.V.d(), h.GRAD.d(), 0, var_par, 0);
@@ -716,7 +722,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
             hipLaunchKernelGGL(k_cm_commit, dim3((C + 63) / 64, p.nchq), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.UP.d(),
                                h.GRADP.d(), h.V.ld, Q, C, h.cm_acc.as<int>());
         } else
-        hipLaunchKernelGGL(k_hmc_accept, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(), h.UP.d(),
+        MCML_FL_DISPATCH(c.flink, k_hmc_accept, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(), h.UP.d(),
                            h.GRADP.d(), h.V.ld, Q, h.MU.d(), h.MU.ld, n, c.y.d(), var_par, c.flink, ca,
                            o->target_accept, adapt, it, C, flags_out ? d_flags.as<uint8_t>() : nullptr,
                            probs_out ? d_probs.d() : nullptr);

@@ -303,9 +303,12 @@ int model_update_L(Ctx& c)
 }
 
 // ------------------------------------------------------------------ log_likelihood
+// FL != 0: the family / link as a compile-time constant (glm_logpdf's 12-way switch inlined costs 288 VGPRs)
+template <int FL>
 __global__ __launch_bounds__(256) void k_loglik(const double* ZU, int ldz, int n, int ncols, const double* xb,
-                                                const double* y, double var_par, int flink, double* partials)
+                                                const double* y, double var_par, int flink_rt, double* partials)
 {
+    const int flink = FL ? FL : flink_rt;
     __shared__ double sh[4];
     int i = blockIdx.x * 256 + threadIdx.x;
     double acc = 0;
@@ -324,7 +327,7 @@ int model_loglik_sum(Ctx& c, double var_par, double* sum_out)
     MCML_TRY(model_update_zu(c));
     int gx = (c.n + 255) / 256, gy = c.niter < 64 ? c.niter : 64;
     MCML_TRY(c.partials.ensure(sizeof(double) * (size_t)(gx * gy + 16)));
-    hipLaunchKernelGGL(k_loglik, dim3(gx, gy), dim3(256), 0, c.stream, c.ZU.d(), c.ZU.ld, c.n, c.niter,
+    MCML_FL_DISPATCH(c.flink, k_loglik, dim3(gx, gy), dim3(256), 0, c.stream, c.ZU.d(), c.ZU.ld, c.n, c.niter,
                        c.xb.d(), c.y.d(), var_par, c.flink, c.partials.d());
     MCML_HIP(hipGetLastError());
     MCML_TRY(device_sum(c, c.partials.d(), gx * gy, c.scalars.d() + 4));

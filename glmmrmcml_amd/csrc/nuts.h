@@ -480,7 +480,7 @@ struct NutsRun {
             hipLaunchKernelGGL(k_cm_lp0_fin, dim3((h.Cw + 63) / 64), dim3(256), 0, c.stream, p.ll, p.lp, p.nchn, p.nchq, p.ldp,
                                h.Cw, nc.lp_new);
         } else
-            hipLaunchKernelGGL(k_hmc_lp0, dim3(h.Cw), dim3(256), 0, c.stream, h.MU.d(), h.MU.ld, c.n, h.UP.d(), h.UP.ld, Q,
+            MCML_FL_DISPATCH(c.flink, k_hmc_lp0, dim3(h.Cw), dim3(256), 0, c.stream, h.MU.d(), h.MU.ld, c.n, h.UP.d(), h.UP.ld, Q,
                                c.y.d(), var_par, c.flink, nc.lp_new);
         MCML_HIP(hipGetLastError());
         return hmc_backward(c, h.UP.d(), h.GRADP.d(), 0, var_par, 0);

@@ -242,14 +242,15 @@ def main():
                                    % ("band" if prof["operator"] == "banded" else "dlds"),
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "launches": launches, "avg_launch_ms": avg_s * 1e3,
+                         "launches": prof["fwd_n_all"] + prof["bwd_n_all"], "launches_timed": launches,
+                         "avg_launch_ms": avg_s * 1e3,
                          "flops_per_launch_executed": executed / max(1, launches),
                          "flops_per_launch_dense_2nQC": prof["dense_flops"],
                          "dense_equivalent_tflops": dense_equiv,
                          "note": "achieved = flops actually executed / kernel time; the banded kernel skips the "
                                  "structurally zero K tiles of the triangular ZL (Z = I), dense_equivalent_tflops "
                                  "prices the same launches at SURVEY 8(d)'s dense 2nQC",
-                         "gemm_share_of_step": gemm_s / dt},
+                         "gemm_share_of_step": avg_s * (prof["fwd_n_all"] + prof["bwd_n_all"]) / dt},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -328,9 +328,13 @@ class Context:
 
     def profile(self, enable=True, reset=False):
         out = np.zeros(8)
+        fa = C.c_longlong(); ba = C.c_longlong()
+        _lib.check(_lib.lib().glmmr_mcml_ctx_profile_launches(self._h, C.byref(fa), C.byref(ba)))
         _lib.check(_lib.lib().glmmr_mcml_ctx_profile(self._h, int(enable), int(reset), _p(out)))
+        # fwd_n / bwd_n: launches that were TIMED (the sampler times one proposal in four); *_all: every launch
         return dict(fwd_ms=out[0], fwd_n=int(out[1]), bwd_ms=out[2], bwd_n=int(out[3]), fwd_flops=out[4],
-                    bwd_flops=out[5], dense_flops=out[6], operator=("dense", "banded", "sparse")[int(out[7])])
+                    bwd_flops=out[5], dense_flops=out[6], operator=("dense", "banded", "sparse")[int(out[7])],
+                    fwd_n_all=fa.value, bwd_n_all=ba.value)
 
 
 def _problem(cov, data, eff_range, Z, X, y, family, link):

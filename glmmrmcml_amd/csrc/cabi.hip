@@ -338,8 +338,16 @@ extern "C" int glmmr_mcml_ctx_profile(glmmr_mcml_ctx* h, int enable, int reset, 
         }
         out8[4] = ff; out8[5] = fb; out8[6] = dense; out8[7] = kind;
     }
-    if (reset) for (int i = 0; i < 4; ++i) { p.ms[i] = 0; p.cnt[i] = 0; }
+    if (reset) for (int i = 0; i < 4; ++i) { p.ms[i] = 0; p.cnt[i] = 0; p.seen[i] = 0; }
     p.on = enable != 0;
+    return MCML_OK;
+}
+
+extern "C" int glmmr_mcml_ctx_profile_launches(glmmr_mcml_ctx* h, long long* fwd, long long* bwd)
+{
+    MCML_REQUIRE(h, "profile_launches: null context");
+    if (fwd) *fwd = h->c.prof.seen[0];
+    if (bwd) *bwd = h->c.prof.seen[1];
     return MCML_OK;
 }
 

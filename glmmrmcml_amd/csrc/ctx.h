@@ -61,6 +61,8 @@ struct SparseZL {
 // (bench.py's roofline line).  kind 0 = HMC forward GEMM, 1 = HMC backward GEMM.
 struct KernelProf {
     bool on = false;
+    bool skip = false;                          // on, but this launch is only counted (the sampler times one proposal in four)
+    long long seen[4] = {0, 0, 0, 0};           // launches since the last reset, timed or not
     std::vector<hipEvent_t> ev;                 // pool
     std::vector<int> kind, e0, e1;              // per timed launch: kind, start / stop event index
     size_t used = 0, nev = 0;
@@ -77,6 +79,8 @@ struct KernelProf {
     // marker costs a few microseconds of idle GPU between dependent kernels)
     int begin(hipStream_t s, int k, bool chain = false) {
         if (!on) return -1;
+        ++seen[k];
+        if (skip) return -1;
         int st = (chain && last_stop >= 0) ? last_stop : fresh();
         if (st < 0) return -1;
         if (!(chain && last_stop >= 0)) (void)hipEventRecord(ev[st], s);

@@ -706,10 +706,16 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
             seen_maxs = maxs;
         }
         MCML_REQUIRE(maxs >= 1 && maxs <= o->max_steps, "hmc: step count %d out of range", maxs);
-        for (int s = 0; s < maxs; ++s) {
-            MCML_TRY(hmc_forward(c, h.UP.d(), h.UP.ld, var_par, s == maxs - 1, s > 0));
-            MCML_TRY(hmc_backward(c, h.UP.d(), h.GRADP.d(), s, var_par, 1, true));
+        // kernel timing (bench.py's roofline): every marker between two dependent launches costs ~2.5 us of idle GPU,
+        // so one proposal in four is timed -- still hundreds of launches per MCML iteration behind the average
+        c.prof.skip = (it & 3) != 0;
+        int rc_traj = MCML_OK;
+        for (int s = 0; s < maxs && rc_traj == MCML_OK; ++s) {
+            rc_traj = hmc_forward(c, h.UP.d(), h.UP.ld, var_par, s == maxs - 1, s > 0);
+            if (rc_traj == MCML_OK) rc_traj = hmc_backward(c, h.UP.d(), h.GRADP.d(), s, var_par, 1, true);
         }
+        c.prof.skip = false;
+        MCML_TRY(rc_traj);
         c.prof.unchain();
         const int adapt = (it < o->warmup) && (it < o->adapt);     // mhmcmc.h:131-136
         if (h.cm) {

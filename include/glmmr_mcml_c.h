@@ -198,6 +198,9 @@ int glmmr_mcml_ctx_ncols(glmmr_mcml_ctx* ctx);
  * executed flops per forward / per backward launch, dense flops per launch (2 n Q C),
  * operator kind: 0 dense GEMM, 1 banded GEMM (structural zeros of ZL skipped), 2 sparse] */
 int glmmr_mcml_ctx_profile(glmmr_mcml_ctx* ctx, int enable, int reset, double* out8);
+/* The sampler TIMES one proposal in four (a marker between two dependent launches costs ~2.5 us of idle GPU): out8's
+ * launch counts are the timed launches; these are all forward / backward launches since the last reset. */
+int glmmr_mcml_ctx_profile_launches(glmmr_mcml_ctx* ctx, long long* fwd, long long* bwd);
 int glmmr_mcml_ctx_npar(glmmr_mcml_ctx* ctx);
 
 /* The same drivers on a resident context (what bench.py times). */

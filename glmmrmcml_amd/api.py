@@ -46,7 +46,7 @@ class HmcDiag(C.Structure):
 
 class NutsOpts(C.Structure):
     _fields_ = [("warmup", C.c_int), ("nsamp", C.c_int), ("max_treedepth", C.c_int), ("adapt_delta", C.c_double),
-                ("stepsize", C.c_double), ("chains", C.c_int), ("chain_offset", C.c_int)]
+                ("stepsize", C.c_double), ("chains", C.c_int), ("chain_offset", C.c_int), ("metric", C.c_int)]
 
 
 class NutsDiag(C.Structure):
@@ -227,10 +227,11 @@ class Context:
         return diag
 
     def nuts_sample(self, beta, var_par, warmup, nsamp, seed, chains=1, chain_offset=0, iter_idx=0, max_treedepth=10,
-                    adapt_delta=0.8, stepsize=1.0, want_trace=False):
+                    adapt_delta=0.8, stepsize=1.0, want_trace=False, metric="diag_e"):
         """the sampler that stands where the reference calls Stan (gen_u_samples.R, inst/stan): csrc/nuts.h"""
         beta = _f(beta).ravel()
-        o = NutsOpts(warmup, nsamp, max_treedepth, adapt_delta, stepsize, chains, chain_offset)
+        o = NutsOpts(warmup, nsamp, max_treedepth, adapt_delta, stepsize, chains, chain_offset,
+                     {"diag_e": 0, "unit_e": 1}[metric])
         d = NutsDiag()
         total = warmup + -(-nsamp // chains)
         c_ip_ = C.POINTER(C.c_int)
@@ -423,7 +424,7 @@ def gen_u_samples(y, X, Z, L, beta, family, link, sigma=1.0, warmup_iter=100, m=
     ncol = chains * -(-int(m) // chains)
     out = np.zeros((Q, ncol), order="F"); nc = C.c_int()
     e = Ext(int(seed), int(chains), 0, 0)
-    o = NutsOpts(int(warmup_iter), int(m), int(max_treedepth), float(adapt_delta), 0.0, int(chains), 0)
+    o = NutsOpts(int(warmup_iter), int(m), int(max_treedepth), float(adapt_delta), 0.0, int(chains), 0, 0)
     _lib.check(_lib.lib().glmmr_mcml_gen_u_samples(_p(Z), _p(Lm), _p(X), _p(y), n, Q, X.shape[1], _p(beta), family.encode(),
                                                    link.encode(), C.c_double(sigma), int(warmup_iter), int(m), C.byref(o),
                                                    C.byref(e), _p(out), Q, C.byref(nc)))

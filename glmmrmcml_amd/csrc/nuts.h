@@ -17,8 +17,12 @@
 //   * step size: Stan's dual averaging on the mean of min(1, exp(H0 - H)) over the leaves (delta, gamma = 0.05,
 //     t0 = 10, kappa = 0.75, mu = log(10 eps0)) during warm-up, eps = exp(xbar) after; eps0 from Stan's doubling /
 //     halving heuristic (init_stepsize).
-// Not reproduced: Stan's metric adaptation (this is `metric = unit_e`), its extra cross-subtree checks (2.23+), its
-// initial values (uniform(-2, 2): the chains here start from N(0, 1) draws like the HMC sampler) and its RNG.  cmdstan
+//   * metric: Stan's default `diag_e` with its windowed adaptation (windowed_adaptation / var_adaptation: Welford
+//     variance of every coordinate over doubling windows between init_buffer and term_buffer, regularised
+//     (n / (n + 5)) var + 1e-3 * 5 / (n + 5); at the end of a window the step size is searched again and the dual
+//     averaging restarts with mu = log(10 eps)); every chain adapts its own diagonal.  `metric = 1` keeps unit_e.
+// Not reproduced: Stan's extra cross-subtree checks (2.23+), its initial values (uniform(-2, 2): the chains here
+// start from N(0, 1) draws like the HMC sampler) and its RNG.  cmdstan
 // does not exist in this image: parity of this sampler is UNPINNED; it is checked against oracle/nuts.py (same
 // algorithm, same streams: every tree depth, leapfrog count and divergence identical) and against the exact
 // posterior of the gaussian model.
@@ -33,7 +37,7 @@ namespace mcml {
 
 struct NutsChain {                                  // per-chain scalars (arrays of Cp)
     double *eps, *H0, *lw_tree, *lw_stack, *lp_new, *sum_acc, *xbar, *sbar, *mu, *dH;
-    int *active, *valid, *dir, *depth, *nleap, *counter, *ndiv, *accsub, *was, *hdir, *hdone, *nhit, *slot;
+    int *active, *valid, *dir, *depth, *nleap, *counter, *ndiv, *accsub, *was, *hdir, *hdone, *nhit, *slot, *ndsave;
     uint8_t* choose;                                // [NUTS_MAXD][Cp]
     uint32_t* gen;
     int Cp;
@@ -42,7 +46,7 @@ struct NutsChain {                                  // per-chain scalars (arrays
 static size_t nuts_chain_bytes(int C)
 {
     const size_t Cp = (size_t)round_up(C, 64);
-    return sizeof(double) * Cp * (10 + NUTS_MAXD + 1) + sizeof(int) * Cp * 14 + (size_t)NUTS_MAXD * Cp + 256;
+    return sizeof(double) * Cp * (10 + NUTS_MAXD + 1) + sizeof(int) * Cp * 15 + (size_t)NUTS_MAXD * Cp + 256;
 }
 static NutsChain nuts_chain(void* base, int C)
 {
@@ -55,9 +59,9 @@ static NutsChain nuts_chain(void* base, int C)
     int* i = reinterpret_cast<int*>(d + (10 + NUTS_MAXD + 1) * Cp);
     a.active = i; a.valid = i + Cp; a.dir = i + 2 * Cp; a.depth = i + 3 * Cp; a.nleap = i + 4 * Cp;
     a.counter = i + 5 * Cp; a.ndiv = i + 6 * Cp; a.accsub = i + 7 * Cp; a.was = i + 8 * Cp; a.hdir = i + 9 * Cp;
-    a.hdone = i + 10 * Cp; a.nhit = i + 11 * Cp; a.slot = i + 12 * Cp;
-    a.gen = reinterpret_cast<uint32_t*>(i + 13 * Cp);
-    a.choose = reinterpret_cast<uint8_t*>(i + 14 * Cp);
+    a.hdone = i + 10 * Cp; a.nhit = i + 11 * Cp; a.slot = i + 12 * Cp; a.ndsave = i + 13 * Cp;
+    a.gen = reinterpret_cast<uint32_t*>(i + 14 * Cp);
+    a.choose = reinterpret_cast<uint8_t*>(i + 15 * Cp);
     a.Cp = (int)Cp;
     return a;
 }
@@ -114,7 +118,8 @@ __device__ __forceinline__ void nuts_store_partials(double (&acc)[NV][NutsTile<C
 struct NutsVecs {                                   // device pointers, all with the leading dimension of the state
     double *TM, *RM, *GM, *TP, *RP, *GP;            // backward / forward edge: position, momentum, gradient
     double *Trho, *Tth;                             // the tree: sum of momenta, proposal
-    double *Crho, *Cpb, *Cth;                       // node under construction: rho, momentum of its first-built end, proposal
+    double *Crho, *Cpb, *Cth;                       // node under construction: rho, M^-1 p of its first-built end, proposal
+    double *Mi, *Wm, *Ws;                           // inverse metric (diagonal, per chain); Welford mean and sum of squares
 };
 
 // iteration start: fresh momentum, one-node tree
@@ -132,12 +137,13 @@ __global__ __launch_bounds__(256) void k_nuts_begin(const double* V, const doubl
         if (!fin || s >= S) continue;
         const int ch = CM ? f : s, q = CM ? s : f;
         const size_t off = f + (size_t)s * ld;
-        const double r = rng_normal(seed, (uint32_t)q, chain_offset + (uint32_t)ch, it, stream);
+        const double mi = nv.Mi[off];
+        const double r = rng_normal(seed, (uint32_t)q, chain_offset + (uint32_t)ch, it, stream) / sqrt(mi);   // diag_e sample_p
         const double v = V[off], g = GRAD[off];
         nv.TM[off] = v; nv.TP[off] = v; nv.Tth[off] = v;
         nv.RM[off] = r; nv.RP[off] = r; nv.Trho[off] = r;
         nv.GM[off] = g; nv.GP[off] = g;
-        acc[0][u] = r * r;
+        acc[0][u] = r * (mi * r);
     }
     nuts_store_partials<CM, 1>(acc, part, pstride, ldp, C);
 }
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256) void k_nuts_leap_pre(NutsVecs nv, double* WX, 
         const double rh = r + (0.5 * es) * g;
         WR[off] = rh;
         const int sl = nc.slot[ch];                                // the products run on the packed columns
-        WX[CM ? sl + (size_t)s * ld : f + (size_t)sl * ld] = th + es * rh;
+        WX[CM ? sl + (size_t)s * ld : f + (size_t)sl * ld] = th + es * (nv.Mi[off] * rh);
     }
 }
 
@@ -191,8 +197,9 @@ __global__ __launch_bounds__(256) void k_nuts_leap_post(const double* WX, const 
         const double rn = WR[off] + (0.5 * es) * g;
         if (d > 0) { nv.TP[off] = x; nv.RP[off] = rn; nv.GP[off] = g; }
         else { nv.TM[off] = x; nv.RM[off] = rn; nv.GM[off] = g; }
-        nv.Crho[off] = rn; nv.Cpb[off] = rn; nv.Cth[off] = x;
-        acc[0][u] = rn * rn;
+        const double ps = nv.Mi[off] * rn;                         // M^-1 p
+        nv.Crho[off] = rn; nv.Cpb[off] = ps; nv.Cth[off] = x;
+        acc[0][u] = rn * ps;
     }
     nuts_store_partials<CM, 1>(acc, part, pstride, ldp, C);
 }
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(256) void k_nuts_merge(const double* Srho, const do
         const size_t off = f + (size_t)s * ld;
         const double rho = Srho[off] + nv.Crho[off];
         const double pb = Spb[off];
-        const double pe = nc.dir[ch] > 0 ? nv.RP[off] : nv.RM[off];
+        const double pe = nv.Mi[off] * (nc.dir[ch] > 0 ? nv.RP[off] : nv.RM[off]);
         nv.Crho[off] = rho; nv.Cpb[off] = pb;
         if (!choose[ch]) nv.Cth[off] = Sth[off];
         acc[0][u] = pb * rho; acc[1][u] = pe * rho;
@@ -241,7 +248,8 @@ __global__ __launch_bounds__(256) void k_nuts_tree_update(const double* Srho, co
         const double rho = nv.Trho[off] + Srho[off];
         nv.Trho[off] = rho;
         if (nc.accsub[ch]) nv.Tth[off] = Sth[off];
-        acc[0][u] = nv.RM[off] * rho; acc[1][u] = nv.RP[off] * rho;
+        const double mi = nv.Mi[off];
+        acc[0][u] = (mi * nv.RM[off]) * rho; acc[1][u] = (mi * nv.RP[off]) * rho;
     }
     nuts_store_partials<CM, 2>(acc, part, pstride, ldp, C);
 }
@@ -259,6 +267,43 @@ __global__ __launch_bounds__(256) void k_nuts_commit(const double* Tth, double* 
     }
 }
 
+// metric adaptation (var_adaptation): Welford update with the state after a transition; end of a window
+template <bool CM>
+__global__ __launch_bounds__(256) void k_nuts_welford(const double* V, NutsVecs nv, int ld, int Q, int C, double nsamp)
+{
+    NUTS_IDX();
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+        const int s = s0 + u;
+        if (!fin || s >= S) continue;
+        const size_t off = f + (size_t)s * ld;
+        const double q = V[off];
+        double m = nv.Wm[off];
+        const double delta = q - m;
+        m = m + delta / nsamp;
+        nv.Wm[off] = m;
+        nv.Ws[off] = nv.Ws[off] + (q - m) * delta;
+    }
+}
+
+template <bool CM>
+__global__ __launch_bounds__(256) void k_nuts_metric(NutsVecs nv, int ld, int Q, int C, double nsamp, int reset_only)
+{
+    NUTS_IDX();
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+        const int s = s0 + u;
+        if (!fin || s >= S) continue;
+        const size_t off = f + (size_t)s * ld;
+        if (reset_only) nv.Mi[off] = 1.0;
+        else {
+            const double var = nv.Ws[off] / (nsamp - 1.0);
+            nv.Mi[off] = (nsamp / (nsamp + 5.0)) * var + 1e-3 * (5.0 / (nsamp + 5.0));
+        }
+        nv.Wm[off] = 0.0; nv.Ws[off] = 0.0;
+    }
+}
+
 // ---- per-chain kernels: a 256-thread workgroup = 64 chains (cm_sum_chunks adds the partial sums), wave 0 decides
 __global__ __launch_bounds__(256) void k_nuts_chain_init(int C, NutsChain nc, double eps0, uint64_t seed, uint32_t chain_offset,
                                                          uint32_t iter_idx)
@@ -266,7 +311,7 @@ __global__ __launch_bounds__(256) void k_nuts_chain_init(int C, NutsChain nc, do
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     nc.eps[c] = eps0; nc.counter[c] = 0; nc.sbar[c] = 0.0; nc.xbar[c] = 0.0; nc.mu[c] = log(10 * eps0);
-    nc.ndiv[c] = 0; nc.nhit[c] = 0; nc.hdone[c] = 0; nc.hdir[c] = 0;
+    nc.ndiv[c] = 0; nc.nhit[c] = 0; nc.hdone[c] = 0; nc.hdir[c] = 0; nc.ndsave[c] = 0;
     nc.gen[c] = chain_minstd_seed(seed, chain_offset + (uint32_t)c, iter_idx);
 }
 
@@ -441,12 +486,20 @@ __global__ __launch_bounds__(256) void k_nuts_heur_fin(int C, NutsChain nc, int 
     }
 }
 
+__global__ __launch_bounds__(256) void k_nuts_heur_reset(int C, NutsChain nc)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    nc.hdone[c] = 0; nc.hdir[c] = 0;
+    nc.ndsave[c] = nc.ndiv[c];                                     // the search's own divergent leaves do not count
+}
 __global__ __launch_bounds__(256) void k_nuts_heur_done(int C, NutsChain nc)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     nc.mu[c] = log(10 * nc.eps[c]);                                // stepsize_adaptation::set_mu
-    nc.ndiv[c] = 0; nc.nhit[c] = 0;
+    nc.counter[c] = 0; nc.sbar[c] = 0.0; nc.xbar[c] = 0.0;         // stepsize_adaptation::restart
+    nc.ndiv[c] = nc.ndsave[c];
 }
 
 __global__ void k_nuts_diag(NutsChain nc, int C, double* out)
@@ -573,10 +626,13 @@ struct NutsRun {
         return MCML_OK;
     }
     // Stan's init_stepsize
+    int nsearch = 0;
     int find_stepsize()
     {
+        hipLaunchKernelGGL(k_nuts_heur_reset, dim3((C + 255) / 256), dim3(256), 0, c.stream, C, nc);
+        const uint32_t base = 1000u * (uint32_t)nsearch++;             // every search draws its own momenta
         for (int round = 0; round < 80; ++round) {
-            MCML_TRY(begin((uint32_t)round, 16u * iter_idx + 5u));
+            MCML_TRY(begin(base + (uint32_t)round, 16u * iter_idx + 5u));
             MCML_TRY(pack(C));
             hipLaunchKernelGGL(k_nuts_begin_doubling, dim3((C + 255) / 256), dim3(256), 0, c.stream, C, nc, 1);
             MCML_TRY(leaf(0));
@@ -615,15 +671,16 @@ int nuts_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_nut
     MCML_TRY(hmc_alloc(c, C));
     ChainArrays ca = chain_arrays(h);
     NutsState& ns = c.nuts;
-    const int nvec = 11 + 3 * (max_depth + 1);
+    const int nvec = 14 + 3 * (max_depth + 1);
+    const bool diag_metric = o->metric == 0;
     for (int i = 0; i < nvec; ++i) MCML_TRY(h.cm ? ns.vecs[i].alloc(C, Q) : ns.vecs[i].alloc(Q, C));
     MCML_TRY(ns.chain.ensure(nuts_chain_bytes(C)));
     NutsRun r{c, h, ns, nuts_chain(ns.chain.p, C), NutsVecs{}};
-    double* v[11];
-    for (int i = 0; i < 11; ++i) v[i] = ns.vecs[i].d();
-    r.nv = NutsVecs{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10]};
+    double* v[14];
+    for (int i = 0; i < 14; ++i) v[i] = ns.vecs[i].d();
+    r.nv = NutsVecs{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12], v[13]};
     for (int l = 0; l <= max_depth; ++l) {
-        r.Srho[l] = ns.vecs[11 + 3 * l].d(); r.Spb[l] = ns.vecs[12 + 3 * l].d(); r.Sth[l] = ns.vecs[13 + 3 * l].d();
+        r.Srho[l] = ns.vecs[14 + 3 * l].d(); r.Spb[l] = ns.vecs[15 + 3 * l].d(); r.Sth[l] = ns.vecs[16 + 3 * l].d();
     }
     r.C = C; r.Q = Q; r.ld = h.V.ld; r.var_par = var_par; r.seed = seed; r.chain_offset = (uint32_t)o->chain_offset;
     r.iter_idx = iter_idx;
@@ -657,8 +714,30 @@ int nuts_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_nut
     hipLaunchKernelGGL(k_nuts_chain_init, dim3((C + 255) / 256), dim3(256), 0, c.stream, C, r.nc, eps0, seed,
                        (uint32_t)o->chain_offset, iter_idx);
     MCML_HIP(hipGetLastError());
+    // unit metric to start with (Stan's diag_e starts from ones too), Welford state cleared
+    if (h.cm) r.vec(k_nuts_metric<true>, r.nv, r.ld, Q, C, 0.0, 1);
+    else r.vec(k_nuts_metric<false>, r.nv, r.ld, Q, C, 0.0, 1);
     MCML_TRY(r.find_stepsize());
-    const long long heur_leaps = r.leapfrogs;
+    long long heur_leaps = r.leapfrogs;
+    // windowed_adaptation (stan/mcmc/windowed_adaptation.hpp): all integer bookkeeping, the same for every chain
+    struct Windows {
+        int W, init = 75, term = 50, base = 25, counter = 0, next = 0, size = 0;
+        explicit Windows(int W_) : W(W_) {
+            if (W >= 20 && init + base + term > W) { init = (int)(0.15 * W); term = (int)(0.1 * W); base = W - (init + term); }
+            next = init + base - 1; size = base;
+        }
+        bool in_window() const { return counter >= init && counter < W - term && counter != W; }
+        bool at_end() const { return counter == next && counter != W; }
+        void compute_next() {
+            if (next == W - term - 1) return;
+            size *= 2;
+            next = counter + size;
+            if (next == W - term - 1) return;
+            const int boundary = next + 2 * size;
+            if (boundary >= W - term) next = W - term - 1;
+        }
+    } win(o->warmup);
+    int wsamp = 0;
 
     long long sum_leap_chain = 0;                                     // filled from the device at the end
     for (int it = 0; it < total; ++it) {
@@ -667,6 +746,27 @@ int nuts_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_nut
         hipLaunchKernelGGL(k_nuts_end_iter, dim3((C + 255) / 256), dim3(256), 0, c.stream, C, r.nc, adapt, last, delta, it,
                            depth_out ? d_depth.as<int>() : nullptr, nleap_out ? d_nleap.as<int>() : nullptr,
                            eps_out ? d_eps.d() : nullptr, accept_out ? d_acc.d() : nullptr);
+        if (adapt && diag_metric) {                                      // var_adaptation::learn_variance
+            if (win.in_window()) {
+                ++wsamp;
+                if (h.cm) r.vec(k_nuts_welford<true>, h.V.d(), r.nv, r.ld, Q, C, (double)wsamp);
+                else r.vec(k_nuts_welford<false>, h.V.d(), r.nv, r.ld, Q, C, (double)wsamp);
+            }
+            const bool update = win.at_end();
+            if (update) {
+                win.compute_next();
+                if (h.cm) r.vec(k_nuts_metric<true>, r.nv, r.ld, Q, C, (double)wsamp, 0);
+                else r.vec(k_nuts_metric<false>, r.nv, r.ld, Q, C, (double)wsamp, 0);
+                wsamp = 0;
+            }
+            ++win.counter;
+            MCML_HIP(hipGetLastError());
+            if (update) {                                                // adapt_diag_e_nuts::transition
+                const long long before = r.leapfrogs;
+                MCML_TRY(r.find_stepsize());
+                heur_leaps += r.leapfrogs - before;
+            }
+        }
         if (it >= o->warmup) {
             const int col = it - o->warmup;
             if (h.cm)

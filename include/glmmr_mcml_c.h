@@ -142,8 +142,8 @@ int glmmr_mcml_ctx_hmc_sample(glmmr_mcml_ctx* ctx, const double* beta, double va
 
 /* No-U-Turn sampler standing where the reference calls Stan through cmdstanr (R/gen_u_samples.R:38-69,
  * R6ModelExtMCML.R:234-257 with inst/stan/mcml_*.stan: gamma ~ std_normal(), y ~ family(Xb + Z L gamma)).
- * Stan's multinomial NUTS with the generalised U-turn criterion and dual-averaging step size, metric = unit_e
- * (csrc/nuts.h lists what is and is not reproduced).  Stan's defaults apply where a field is 0. */
+ * Stan's multinomial NUTS with the generalised U-turn criterion, dual-averaging step size and diag_e metric
+ * adaptation (csrc/nuts.h lists what is and is not reproduced).  Stan's defaults apply where a field is 0. */
 typedef struct glmmr_mcml_nuts_opts {
     int    warmup;          /* iter_warmup */
     int    nsamp;           /* iter_sampling: draws wanted in total */
@@ -152,6 +152,7 @@ typedef struct glmmr_mcml_nuts_opts {
     double stepsize;        /* initial step size before the init_stepsize search; 0 -> 1 */
     int    chains;          /* C chains x ceil(nsamp/C) draws each; u is Q x C*ceil(nsamp/C) (no column 0) */
     int    chain_offset;    /* global id of this rank's first chain */
+    int    metric;          /* 0: diag_e with Stan's windowed adaptation (its default); 1: unit_e */
 } glmmr_mcml_nuts_opts;
 
 typedef struct glmmr_mcml_nuts_diag {

@@ -10,8 +10,11 @@ as the device code, one chain at a time in plain Python, so that tree depths, le
 accepted subtrees can be compared transition by transition.  Log density and gradient: oracle.log_prob / log_grad
 (mcmlmodel.h:138-153, 156-279).
 
+Metric: diag_e with Stan's windowed adaptation (windowed_adaptation.hpp, var_adaptation.hpp, welford_var_estimator.hpp,
+adapt_diag_e_nuts.hpp), or unit_e.
 Streams (shared with csrc/nuts.h): initial state rng_normal(seed, q, chain, 0, 16 iter_idx + 0); momentum of transition
-`it` tag 16 iter_idx + 4; momentum of step-size search round r tag 16 iter_idx + 5 with prop = r; uniforms from the
+`it` tag 16 iter_idx + 4 (divided by sqrt of the inverse metric); momentum of round r of the k-th step-size search tag
+16 iter_idx + 5 with prop = 1000 k + r; uniforms from the
 chain's minstd stream in the order: direction of a doubling; one draw per merge of a leaf (levels ascending); one
 draw for the tree-level acceptance only when the subtree is not heavier than the tree.
 """
@@ -46,8 +49,35 @@ class _Stream:
         return self.L.orc_minstd_canonical(C.byref(self.x))
 
 
+class _Windows:
+    """stan/mcmc/windowed_adaptation.hpp"""
+
+    def __init__(self, W):
+        self.W, self.init, self.term, self.base, self.counter = W, 75, 50, 25, 0
+        if W >= 20 and self.init + self.base + self.term > W:
+            self.init = int(0.15 * W); self.term = int(0.1 * W); self.base = W - (self.init + self.term)
+        self.next = self.init + self.base - 1
+        self.size = self.base
+
+    def in_window(self):
+        return self.counter >= self.init and self.counter < self.W - self.term and self.counter != self.W
+
+    def at_end(self):
+        return self.counter == self.next and self.counter != self.W
+
+    def compute_next(self):
+        if self.next == self.W - self.term - 1:
+            return
+        self.size *= 2
+        self.next = self.counter + self.size
+        if self.next == self.W - self.term - 1:
+            return
+        if self.next + 2 * self.size >= self.W - self.term:
+            self.next = self.W - self.term - 1
+
+
 def nuts_chain(xb, ZL, y, var_par, fl, warmup, ndraw, seed, chain_id=0, iter_idx=0, max_treedepth=10, adapt_delta=0.8,
-               stepsize=1.0):
+               stepsize=1.0, metric="diag_e"):
     """one chain: returns (draws Q x ndraw of gamma, trace dict of per-transition depth / nleap / eps / accept,
     diag dict)"""
     xb = np.ascontiguousarray(xb, dtype=float); y = np.ascontiguousarray(y, dtype=float)
@@ -60,48 +90,61 @@ def nuts_chain(xb, ZL, y, var_par, fl, warmup, ndraw, seed, chain_id=0, iter_idx
 
     theta = normal(0, 16 * iter_idx + 0)
     eps = float(stepsize)
+    mi = np.ones(Q)                                               # inverse metric (diag_e starts from ones)
 
     def leapfrog(th, r, g, es):
         rh = r + (0.5 * es) * g
-        x = th + es * rh
+        x = th + es * (mi * rh)
         gn = gr_f(x)
         rn = rh + (0.5 * es) * gn
         return x, rn, gn
 
+    def kinetic2(r):
+        return float(np.dot(r, mi * r))
+
     def energy(x, r):
-        h = -1 * lp_f(x) + 0.5 * float(np.dot(r, r))
+        h = -1 * lp_f(x) + 0.5 * kinetic2(r)
         return math.inf if math.isnan(h) else h
 
     # ---- init_stepsize (base_hmc.hpp)
     thr = math.log(0.8)
-    direction = 0
-    search_leaps = 0
-    for rnd in range(80):
-        r0 = normal(rnd, 16 * iter_idx + 5)
-        H0 = -1 * lp_f(theta) + 0.5 * float(np.dot(r0, r0))
-        x, rn, _ = leapfrog(theta, r0, gr_f(theta), eps)
-        search_leaps += 1
-        dH = H0 - energy(x, rn)
-        if rnd == 0:
-            direction = 1 if dH > thr else -1
-            continue
-        if (direction == 1 and not dH > thr) or (direction == -1 and not dH < thr):
-            break
-        e2 = 2 * eps if direction == 1 else 0.5 * eps
-        if e2 > 1e7 or e2 < 1e-300:
-            break
-        eps = e2
+    state = dict(search_leaps=0, nsearch=0)
+
+    def find_stepsize(eps):
+        base = 1000 * state["nsearch"]
+        state["nsearch"] += 1
+        direction = 0
+        for rnd in range(80):
+            r0 = normal(base + rnd, 16 * iter_idx + 5) / np.sqrt(mi)
+            H0 = -1 * lp_f(theta) + 0.5 * kinetic2(r0)
+            x, rn, _ = leapfrog(theta, r0, gr_f(theta), eps)
+            state["search_leaps"] += 1
+            dH = H0 - energy(x, rn)
+            if rnd == 0:
+                direction = 1 if dH > thr else -1
+                continue
+            if (direction == 1 and not dH > thr) or (direction == -1 and not dH < thr):
+                break
+            e2 = 2 * eps if direction == 1 else 0.5 * eps
+            if e2 > 1e7 or e2 < 1e-300:
+                break
+            eps = e2
+        return eps
+
+    eps = find_stepsize(eps)
     mu = math.log(10 * eps)
     counter, sbar, xbar = 0, 0.0, 0.0
+    win = _Windows(warmup)
+    wn, wm, ws = 0, np.zeros(Q), np.zeros(Q)
 
     total = warmup + ndraw
     draws = np.zeros((Q, ndraw), order="F")
     tr = dict(depth=np.zeros(total, dtype=int), nleap=np.zeros(total, dtype=int), eps=np.zeros(total),
               accept=np.zeros(total), ndiv=0, nhit=0)
     for it in range(total):
-        r0 = normal(it, 16 * iter_idx + 4)
+        r0 = normal(it, 16 * iter_idx + 4) / np.sqrt(mi)
         g0 = gr_f(theta)
-        H0 = -1 * lp_f(theta) + 0.5 * float(np.dot(r0, r0))
+        H0 = -1 * lp_f(theta) + 0.5 * kinetic2(r0)
         tm, rm, gm = theta.copy(), r0.copy(), g0.copy()          # backward edge
         tp, rp, gp = theta.copy(), r0.copy(), g0.copy()          # forward edge
         t_rho, t_th, lw_tree = r0.copy(), theta.copy(), 0.0
@@ -132,14 +175,14 @@ def nuts_chain(xb, ZL, y, var_par, fl, warmup, ndraw, seed, chain_id=0, iter_idx
                     lwm = _logaddexp(stack[l][3], lw)
                     choose.append(gen.u() < math.exp(lw - lwm))
                     lw = lwm
-                rho, pb, th = rn.copy(), rn.copy(), x.copy()
+                rho, pb, th = rn.copy(), mi * rn, x.copy()          # pb: M^-1 p of the first-built end
                 for l in range(tz):
                     s_rho, s_pb, s_th, _ = stack[l]
                     rho = s_rho + rho
                     pb = s_pb
                     if not choose[l]:
                         th = s_th
-                    if not (float(np.dot(pb, rho)) > 0 and float(np.dot(rn, rho)) > 0):
+                    if not (float(np.dot(pb, rho)) > 0 and float(np.dot(mi * rn, rho)) > 0):
                         valid = False
                         break
                 if not valid:
@@ -158,7 +201,7 @@ def nuts_chain(xb, ZL, y, var_par, fl, warmup, ndraw, seed, chain_id=0, iter_idx
             t_rho = t_rho + s_rho
             if acc:
                 t_th = s_th
-            if not (float(np.dot(rm, t_rho)) > 0 and float(np.dot(rp, t_rho)) > 0):
+            if not (float(np.dot(mi * rm, t_rho)) > 0 and float(np.dot(mi * rp, t_rho)) > 0):
                 active = False
                 break
             if depth >= max_treedepth:
@@ -176,7 +219,24 @@ def nuts_chain(xb, ZL, y, var_par, fl, warmup, ndraw, seed, chain_id=0, iter_idx
             xeta = counter ** -0.75
             xbar = (1.0 - xeta) * xbar + xeta * xx
             eps = math.exp(xbar) if it == warmup - 1 else math.exp(xx)
+            if metric == "diag_e":                                # var_adaptation::learn_variance
+                if win.in_window():
+                    wn += 1
+                    delta = theta - wm
+                    wm = wm + delta / wn
+                    ws = ws + (theta - wm) * delta
+                update = win.at_end()
+                if update:
+                    win.compute_next()
+                    var = ws / (wn - 1.0)
+                    mi = (wn / (wn + 5.0)) * var + 1e-3 * (5.0 / (wn + 5.0))
+                    wn, wm, ws = 0, np.zeros(Q), np.zeros(Q)
+                win.counter += 1
+                if update:                                        # adapt_diag_e_nuts::transition
+                    eps = find_stepsize(eps)
+                    mu = math.log(10 * eps)
+                    counter, sbar, xbar = 0, 0.0, 0.0
         tr["accept"][it] = stat
         if it >= warmup:
             draws[:, it - warmup] = theta
-    return draws, tr, dict(eps=eps, search_leaps=search_leaps)
+    return draws, tr, dict(eps=eps, search_leaps=state["search_leaps"], inv_metric=mi)

@@ -3,8 +3,8 @@
 
 PARITY UNPINNED: cmdstan does not exist in this image and the reference holds no Stan output.  The oracle restates the
 published algorithm with the device's random streams; every transition's tree depth and leapfrog count must be
-identical, step sizes within 1e-9 relative and draws within 1e-7 (f64, different summation orders; no decision in these
-seeded cases sits within rounding of its threshold).  The exact gaussian posterior is the known answer."""
+identical, step sizes within 1e-9 relative and draws within 1e-7 for the short runs, 1e-5 / 1e-3 after 24 adaptive
+transitions (f64, different summation orders; no decision in these seeded cases sits within rounding of its threshold).  The exact gaussian posterior is the known answer."""
 import numpy as np
 import pytest
 
@@ -25,27 +25,36 @@ CASES = [(synth.geospatial, dict(n=96), 0.9),                                  #
          (synth.stepped_wedge, dict(ncl=6, nt=4, nind=30), 1.0)]               # sparse ZL as two factors
 
 
+# warm-up 14: fewer than 20 transitions, Stan adapts the step size only; 24: init_buffer 3, one window of 19
+# transitions whose end (transition 21) replaces the metric, searches the step size again and restarts the dual
+# averaging, term_buffer 2; unit_e: the same 24 transitions without metric adaptation
+@pytest.mark.parametrize("warm,metric", [(14, "diag_e"), (24, "diag_e"), (24, "unit_e")])
 @pytest.mark.parametrize("gen,kw,vp", CASES)
-def test_chains_match_oracle_transition_by_transition(orc, gen, kw, vp):
+def test_chains_match_oracle_transition_by_transition(orc, gen, kw, vp, warm, metric):
     from glmmrmcml_amd import api
     from oracle import nuts
     d = gen(**kw)
     ctx, ZL, xb, fl, Lo = _setup(orc, d, api)
-    Cn, warm, nsamp, seed, it, md = 4, 14, 12, 20240607, 3, 6
+    Cn, nsamp, seed, it, md = 4, 12, 20240607, 3, 6
     diag, tr = ctx.nuts_sample(d["beta"], vp, warm, nsamp, seed, chains=Cn, chain_offset=5, iter_idx=it, max_treedepth=md,
-                               want_trace=True)
+                               want_trace=True, metric=metric)
     u = ctx.get_u()
     dpc = 3
     assert u.shape == (d["Q"], Cn * dpc)
     ndiv = nhit = 0
     for c in range(Cn):
-        so, to, dg = nuts.nuts_chain(xb, ZL, d["y"], vp, fl, warm, dpc, seed, chain_id=5 + c, iter_idx=it, max_treedepth=md)
+        so, to, dg = nuts.nuts_chain(xb, ZL, d["y"], vp, fl, warm, dpc, seed, chain_id=5 + c, iter_idx=it, max_treedepth=md,
+                                     metric=metric)
         assert np.array_equal(tr["depth"][c], to["depth"]), (c, tr["depth"][c], to["depth"])
         assert np.array_equal(tr["nleap"][c], to["nleap"]), (c, tr["nleap"][c], to["nleap"])
-        assert np.abs(tr["eps"][c] / to["eps"] - 1).max() < 1e-9
-        assert np.abs(tr["accept"][c] - to["accept"]).max() < 1e-9
+        # rounding differences of the acceptance statistic go through the dual averaging (gain sqrt(t) / 0.05 on log eps)
+        # and the trajectories amplify them (a factor ~10 every few transitions on the poisson case): 1e-9 after 14
+        # transitions, up to 2e-6 after 30 observed -- the integer decisions (depth, leapfrog count) stay identical
+        tol = 1e-9 if warm < 20 else 1e-5
+        assert np.abs(tr["eps"][c] / to["eps"] - 1).max() < tol
+        assert np.abs(tr["accept"][c] - to["accept"]).max() < tol
         uo = Lo @ so
-        assert np.abs(u[:, c * dpc:(c + 1) * dpc] - uo).max() < 1e-7 * max(1.0, np.abs(uo).max())
+        assert np.abs(u[:, c * dpc:(c + 1) * dpc] - uo).max() < 100 * tol * max(1.0, np.abs(uo).max())
         ndiv += to["ndiv"]; nhit += to["nhit"]
     assert diag["divergent"] == ndiv and diag["treedepth_hits"] == nhit
     assert tr["depth"].max() >= 2                       # the trees did grow
@@ -66,7 +75,8 @@ def test_many_chains_recover_gaussian_posterior(orc):
     se = np.sqrt(np.diag(S) / 1024)
     assert np.all(np.abs(v.mean(1) - mu) < 5 * se)
     assert np.abs(np.cov(v) - S).max() < 0.12 * np.abs(S).max()
-    assert diag["divergent"] < 0.02 * 1024 * 61 and 1e-3 < diag["mean_e"] < 10      # the first warm-up steps may diverge
+    # dual averaging opens, and reopens after the metric update, near 10 x the searched step size: early divergences
+    assert diag["divergent"] < 0.06 * 1024 * 61 and 1e-3 < diag["mean_e"] < 10
     ctx.close()
 
 

@@ -338,9 +338,17 @@ int model_loglik_sum(Ctx& c, double var_par, double* sum_out)
 
 // ------------------------------------------------------------------ MCNR statistics
 // one workgroup per sample column: sigma_i = sd(y - h^-1(xb + zd_i)) (mcmloptim.h:214-216)
+// FL != 0 (k_mcnr_col / k_mcnr_row): family / link as compile-time constants -- flink 1, 3, 7 are poisson/log,
+// binomial/logit, gaussian/identity, whose link codes are 1, 3, 2.  With run-time codes the 16-fold unrolled body of
+// k_mcnr_row is sixteen copies of three switch statements (jump tables, ~1100 basic blocks): 37 us at config 3
+template <int FL>
+__device__ __forceinline__ int mcnr_link(int link_code) { return FL == 1 ? 1 : FL == 3 ? 3 : FL == 7 ? 2 : link_code; }
+
+template <int FL>
 __global__ __launch_bounds__(256) void k_mcnr_col(const double* ZU, int ldz, int n, const double* xb,
-                                                  const double* y, int link_code, double* sig)
+                                                  const double* y, int link_code_rt, double* sig)
 {
+    const int link_code = mcnr_link<FL>(link_code_rt);
     __shared__ double sh[4];
     __shared__ double mean_s;
     const double* z = ZU + (size_t)blockIdx.x * ldz;
@@ -364,10 +372,13 @@ __global__ __launch_bounds__(256) void k_mcnr_col(const double* ZU, int ldz, int
 // k_mcnr_rowsum adds the chunks in order (fixed-order two-stage reduction: n/256 workgroups with a serial loop
 // over all m columns ran at 1 % of the HBM rate)
 constexpr int MCNR_CHUNK = 16;
+template <int FL>
 __global__ __launch_bounds__(256) void k_mcnr_row(const double* ZU, int ldz, int n, int ncols, const double* xb,
-                                                  const double* y, int flink, int link_code, double nvar_par,
+                                                  const double* y, int flink_rt, int link_code_rt, double nvar_par,
                                                   double* pw, double* pwu, int ldp)
 {
+    const int flink = FL ? FL : flink_rt;
+    const int link_code = mcnr_link<FL>(link_code_rt);
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const double yj = y[j], xbj = xb[j];
@@ -391,10 +402,18 @@ __global__ __launch_bounds__(256) void k_mcnr_row(const double* ZU, int ldz, int
 __global__ __launch_bounds__(256) void k_mcnr_rowsum(const double* pw, const double* pwu, int ldp, int n, int nchunks,
                                                      double* wsum, double* wusum)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;           // one wave per workgroup: n / 64 workgroups
     if (j >= n) return;
     double a = 0, b = 0;
-    for (int k = 0; k < nchunks; ++k) { a += pw[j + (size_t)k * ldp]; b += pwu[j + (size_t)k * ldp]; }
+    int k = 0;
+    for (; k + 8 <= nchunks; k += 8) {                              // eight loads of each array in flight, adds in order
+        double va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { va[u] = pw[j + (size_t)(k + u) * ldp]; vb[u] = pwu[j + (size_t)(k + u) * ldp]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a += va[u]; b += vb[u]; }
+    }
+    for (; k < nchunks; ++k) { a += pw[j + (size_t)k * ldp]; b += pwu[j + (size_t)k * ldp]; }
     wsum[j] = a; wusum[j] = b;
 }
 
@@ -439,11 +458,11 @@ int model_mcnr_stats(Ctx& c, double var_par, double* stats)
     double* pw = sig + round_up(m + 16, 32);
     double* pwu = pw + (size_t)nchunks * ldp;
     MCML_TRY(c.reduce_buf.ensure(sizeof(double) * (size_t)ns));
-    hipLaunchKernelGGL(k_mcnr_col, dim3(m), dim3(256), 0, c.stream, c.ZU.d(), c.ZU.ld, n, c.xb.d(), c.y.d(),
-                       c.link_code, sig);
-    hipLaunchKernelGGL(k_mcnr_row, dim3((n + 255) / 256, nchunks), dim3(256), 0, c.stream, c.ZU.d(), c.ZU.ld, n, m,
-                       c.xb.d(), c.y.d(), c.flink, c.link_code, nvar_par, pw, pwu, ldp);
-    hipLaunchKernelGGL(k_mcnr_rowsum, dim3((n + 255) / 256), dim3(256), 0, c.stream, pw, pwu, ldp, n, nchunks, wsum, wusum);
+    MCML_FL_DISPATCH(c.flink, k_mcnr_col, dim3(m), dim3(256), 0, c.stream, c.ZU.d(), c.ZU.ld, n, c.xb.d(), c.y.d(),
+                     c.link_code, sig);
+    MCML_FL_DISPATCH(c.flink, k_mcnr_row, dim3((n + 255) / 256, nchunks), dim3(256), 0, c.stream, c.ZU.d(), c.ZU.ld, n, m,
+                     c.xb.d(), c.y.d(), c.flink, c.link_code, nvar_par, pw, pwu, ldp);
+    hipLaunchKernelGGL(k_mcnr_rowsum, dim3((n + 63) / 64), dim3(64), 0, c.stream, pw, pwu, ldp, n, nchunks, wsum, wusum);
     hipLaunchKernelGGL(k_mcnr_fin, dim3(ns), dim3(256), 0, c.stream, c.X.d(), c.X.ld, n, P, wsum, wusum, sig, m,
                        c.reduce_buf.d());
     MCML_HIP(hipGetLastError());

@@ -103,7 +103,7 @@ __device__ __forceinline__ double glm_digamma(double x)
 // after the product, glm_score_post).  Literally: the reference's second line reads the UPDATED mu(i) = p, so
 // the leading factor is p/(1+exp(p)).  Kept out of glm_score's switch so that the hot GEMM epilogues of the
 // other eleven cases do not carry the digamma loops (they cost the forward band kernel 13 VGPRs and a scratch
-// frame); callers select it with a compile-time flag (EpiForwardT<true>).
+// frame); callers select it at compile time (EpiForwardT<12>).
 __device__ __forceinline__ double glm_score_beta(double y, double mu, double var_par)
 {
     const double p = exp(mu) / (exp(mu) + 1);

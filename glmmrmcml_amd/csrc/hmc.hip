@@ -52,12 +52,15 @@ static ChainArrays chain_arrays(const HmcState& h)
 // store_mu = 0: inside a leapfrog trajectory only the score feeds the next product; the linear
 // predictor itself is read (by k_hmc_accept) after the LAST step only, so its 8 n C bytes per
 // launch are not written
-template <bool BETA>
+// FL: the family / link code as a compile-time constant (12 = beta/logit, whose digamma score is its own function,
+// glm.h; 1, 3, 7 = poisson/log, binomial/logit, gaussian/identity), 0 = run-time code: the epilogue evaluates the score
+// 20 times per lane, unrolled -- with a run-time code that is twenty copies of glm_score's switch
+template <int FL>
 struct EpiForwardT {
     double* MU; double* S; int ld; const double* xb; const double* y; int flink; int store_mu; double var_par;
     __device__ __forceinline__ double score(double yv, double mu) const {
-        if constexpr (BETA) return glm_score_beta(yv, mu, var_par);
-        else return glm_score(yv, mu, flink);
+        if constexpr (FL == 12) return glm_score_beta(yv, mu, var_par);
+        else return glm_score(yv, mu, FL ? FL : flink);
     }
     __device__ __forceinline__ void elem(int m, int n, double accv) const {
         const double mu = xb[m] + accv;
@@ -493,12 +496,18 @@ static int hmc_forward(Ctx& c, const double* X, int ldx, double var_par, bool st
             hipLaunchKernelGGL((k_cm_forward<false>), grid, dim3(256), 0, c.stream, c.n, h.Cw, h.V.ld, W, col, val, Xin, c.xb.d(),
                                c.y.d(), c.flink, var_par, store_mu ? 1 : 0, h.MU.d(), h.S.d(), rpw);
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
-    } else if (c.flink == 12)      // beta/logit: the digamma score is its own instantiation (glm.h)
-        rc = hmc_forward_launch(c, X, ldx, EpiForwardT<true>{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink,
-                                                             store_mu ? 1 : 0, var_par});
-    else
-        rc = hmc_forward_launch(c, X, ldx, EpiForwardT<false>{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink,
-                                                              store_mu ? 1 : 0, var_par});
+    } else {
+#define MCML_FWD(FL) rc = hmc_forward_launch(c, X, ldx, EpiForwardT<FL>{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink, \
+                                                                        store_mu ? 1 : 0, var_par})
+        switch (c.flink) {
+        case 1: MCML_FWD(1); break;
+        case 3: MCML_FWD(3); break;
+        case 7: MCML_FWD(7); break;
+        case 12: MCML_FWD(12); break;
+        default: MCML_FWD(0); break;
+        }
+#undef MCML_FWD
+    }
     c.prof.end(c.stream, slot);
     return rc;
 }

@@ -489,12 +489,16 @@ static int hmc_forward(Ctx& c, const double* X, int ldx, double var_par, bool st
                                c.sp.row_start.as<int>(), c.L.d(), c.L.ld, X, h.LX.d());
             W = c.z_width; col = c.z_idx.as<int>(); val = c.z_val.d(); Xin = h.LX.d();
         }
-        if (c.flink == 12)
-            hipLaunchKernelGGL((k_cm_forward<true>), grid, dim3(256), 0, c.stream, c.n, h.Cw, h.V.ld, W, col, val, Xin, c.xb.d(),
-                               c.y.d(), c.flink, var_par, store_mu ? 1 : 0, h.MU.d(), h.S.d(), rpw);
-        else
-            hipLaunchKernelGGL((k_cm_forward<false>), grid, dim3(256), 0, c.stream, c.n, h.Cw, h.V.ld, W, col, val, Xin, c.xb.d(),
-                               c.y.d(), c.flink, var_par, store_mu ? 1 : 0, h.MU.d(), h.S.d(), rpw);
+#define MCML_CMF(FL) hipLaunchKernelGGL((k_cm_forward<FL>), grid, dim3(256), 0, c.stream, c.n, h.Cw, h.V.ld, W, col, val, Xin, \
+                                        c.xb.d(), c.y.d(), c.flink, var_par, store_mu ? 1 : 0, h.MU.d(), h.S.d(), rpw)
+        switch (c.flink) {
+        case 1: MCML_CMF(1); break;
+        case 3: MCML_CMF(3); break;
+        case 7: MCML_CMF(7); break;
+        case 12: MCML_CMF(12); break;
+        default: MCML_CMF(0); break;
+        }
+#undef MCML_CMF
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
     } else {
 #define MCML_FWD(FL) rc = hmc_forward_launch(c, X, ldx, EpiForwardT<FL>{h.MU.d(), h.S.d(), h.MU.ld, c.xb.d(), c.y.d(), c.flink, \

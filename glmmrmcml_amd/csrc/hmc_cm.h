@@ -63,7 +63,7 @@ __device__ __forceinline__ void sload_f64x2(const double* a, const double* b, do
 // a wave owns CM_FR consecutive observations: the k loop is outermost so that CM_FR independent gathers are in
 // flight per iteration, then CM_FR independent scores and stores
 constexpr int CM_FR = 4;       // 8 measured slower (152 vs 121 us at config 5)
-template <bool BETA>
+template <int FL>      // family / link code at compile time (12 = beta/logit), 0 = run-time code (EpiForwardT, hmc.hip)
 __global__ __launch_bounds__(256) void k_cm_forward(int n, int C, int ldc, int W, const int* col, const double* val,
                                                     const double* X, const double* xb, const double* y, int flink,
                                                     double var_par, int store_mu, double* MU, double* S, int rpw)
@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void k_cm_forward(int n, int C, int ldc, int W
             const double mu = xbi + acc[r];
             const size_t off = c + (size_t)i * ldc;
             if (store_mu) MU[off] = mu;
-            S[off] = BETA ? glm_score_beta(yi, mu, var_par) : glm_score(yi, mu, flink);
+            if constexpr (FL == 12) S[off] = glm_score_beta(yi, mu, var_par);
+            else S[off] = glm_score(yi, mu, FL ? FL : flink);
         }
     }
 }

@@ -34,7 +34,7 @@ struct HmcState {
 // per-chain scalars, partial sums
 constexpr int NUTS_MAXD = 12;                       // deepest tree supported (Stan's default max_treedepth: 10)
 struct NutsState {
-    DevMat vecs[14 + 3 * (NUTS_MAXD + 1)];
+    DevMat vecs[16 + 4 * (NUTS_MAXD + 1)];
     DevBuf chain, part;
 };
 

@@ -9,7 +9,7 @@
 //     at the same (doubling j, leaf n), so ONE batched leapfrog (two products over all chains) extends every tree;
 //   * a leaf has weight exp(H0 - H); a chain whose leaf has H - H0 > 1000 is divergent and stops;
 //   * balanced subtrees are merged like the carries of a binary counter: after leaf n, one merge per trailing one bit
-//     of n.  A merge adds the momentum sums (rho), keeps the earlier-built end's momentum, picks the later subtree's
+//     of n.  A merge adds the momentum sums (rho), keeps the earlier-built begin and the later-built end, picks the later subtree's
 //     proposal with probability w_right / (w_left + w_right), and applies the generalised no-U-turn criterion
 //     p_begin . rho > 0 && p_end . rho > 0 ; a subtree that turns invalidates the doubling and stops the chain;
 //   * a completed doubling replaces the tree's proposal with probability min(1, w_subtree / w_tree) (biased
@@ -21,8 +21,11 @@
 //     variance of every coordinate over doubling windows between init_buffer and term_buffer, regularised
 //     (n / (n + 5)) var + 1e-3 * 5 / (n + 5); at the end of a window the step size is searched again and the dual
 //     averaging restarts with mu = log(10 eps)); every chain adapts its own diagonal.  `metric = 1` keeps unit_e.
-// Not reproduced: Stan's extra cross-subtree checks (2.23+), its initial values (uniform(-2, 2): the chains here
-// start from N(0, 1) draws like the HMC sampler) and its RNG.  cmdstan
+//   * every merge (and the tree itself after every doubling) also applies Stan's checks BETWEEN the two subtrees
+//     (base_nuts.hpp since 2.23): rho_left + p_first(right) against the sharp momenta of left's begin and right's begin,
+//     and rho_right + p_last(left) against left's end and right's end.
+// Not reproduced: Stan's initial values (uniform(-2, 2): the chains here start from N(0, 1) draws like the HMC
+// sampler) and its RNG.  cmdstan
 // does not exist in this image: parity of this sampler is UNPINNED; it is checked against oracle/nuts.py (same
 // algorithm, same streams: every tree depth, leapfrog count and divergence identical) and against the exact
 // posterior of the gaussian model.
@@ -118,8 +121,9 @@ __device__ __forceinline__ void nuts_store_partials(double (&acc)[NV][NutsTile<C
 struct NutsVecs {                                   // device pointers, all with the leading dimension of the state
     double *TM, *RM, *GM, *TP, *RP, *GP;            // backward / forward edge: position, momentum, gradient
     double *Trho, *Tth;                             // the tree: sum of momenta, proposal
-    double *Crho, *Cpb, *Cth;                       // node under construction: rho, M^-1 p of its first-built end, proposal
+    double *Crho, *Cpb, *Cpe, *Cth;                 // node under construction: rho, momentum of its first- / last-built leaf, proposal
     double *Mi, *Wm, *Ws;                           // inverse metric (diagonal, per chain); Welford mean and sum of squares
+    double *Tadj;                                   // momentum of the tree's edge the current doubling grows from (before it)
 };
 
 // iteration start: fresh momentum, one-node tree
@@ -197,61 +201,93 @@ __global__ __launch_bounds__(256) void k_nuts_leap_post(const double* WX, const 
         const double rn = WR[off] + (0.5 * es) * g;
         if (d > 0) { nv.TP[off] = x; nv.RP[off] = rn; nv.GP[off] = g; }
         else { nv.TM[off] = x; nv.RM[off] = rn; nv.GM[off] = g; }
-        const double ps = nv.Mi[off] * rn;                         // M^-1 p
-        nv.Crho[off] = rn; nv.Cpb[off] = ps; nv.Cth[off] = x;
-        acc[0][u] = rn * ps;
+        nv.Crho[off] = rn; nv.Cpb[off] = rn; nv.Cpe[off] = rn; nv.Cth[off] = x;
+        acc[0][u] = rn * (nv.Mi[off] * rn);
     }
     nuts_store_partials<CM, 1>(acc, part, pstride, ldp, C);
 }
 
-// merge the stored node of a level (built earlier) with the node under construction (built later)
+// merge the stored node of a level (built earlier: "left") with the node under construction (built later: "right").
+// Six dot products: around the merged subtree, and the two checks between the subtrees.
 template <bool CM>
-__global__ __launch_bounds__(256) void k_nuts_merge(const double* Srho, const double* Spb, const double* Sth, NutsVecs nv,
-                                                    const uint8_t* choose, int ld, int Q, int C, NutsChain nc, double* part,
-                                                    size_t pstride, int ldp)
+__global__ __launch_bounds__(256) void k_nuts_merge(const double* Srho, const double* Spb, const double* Spe, const double* Sth,
+                                                    NutsVecs nv, const uint8_t* choose, int ld, int Q, int C, NutsChain nc,
+                                                    double* part, size_t pstride, int ldp)
 {
     NUTS_IDX();
-    double acc[2][SB];
+    double acc[6][SB];
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
-        acc[0][u] = 0.0; acc[1][u] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k][u] = 0.0;
         const int s = s0 + u;
         if (!fin || s >= S) continue;
         const int ch = CM ? f : s;
         if (!nc.active[ch]) continue;
         const size_t off = f + (size_t)s * ld;
-        const double rho = Srho[off] + nv.Crho[off];
-        const double pb = Spb[off];
-        const double pe = nv.Mi[off] * (nc.dir[ch] > 0 ? nv.RP[off] : nv.RM[off]);
-        nv.Crho[off] = rho; nv.Cpb[off] = pb;
+        const double mi = nv.Mi[off];
+        const double lrho = Srho[off], rrho = nv.Crho[off];
+        const double lpb = Spb[off], lpe = Spe[off], rpb = nv.Cpb[off], rpe = nv.Cpe[off];
+        const double rho = lrho + rrho;
+        nv.Crho[off] = rho; nv.Cpb[off] = lpb;                      // the end stays the right subtree's
         if (!choose[ch]) nv.Cth[off] = Sth[off];
-        acc[0][u] = pb * rho; acc[1][u] = pe * rho;
+        acc[0][u] = (mi * lpb) * rho; acc[1][u] = (mi * rpe) * rho;
+        const double e1 = lrho + rpb;                              // rho_left + first momentum of the right subtree
+        acc[2][u] = (mi * lpb) * e1; acc[3][u] = (mi * rpb) * e1;
+        const double e2 = rrho + lpe;                              // rho_right + last momentum of the left subtree
+        acc[4][u] = (mi * lpe) * e2; acc[5][u] = (mi * rpe) * e2;
     }
-    nuts_store_partials<CM, 2>(acc, part, pstride, ldp, C);
+    nuts_store_partials<CM, 6>(acc, part, pstride, ldp, C);
 }
 
-// a completed doubling joins the tree
+// the edge a doubling grows from, before it grows
 template <bool CM>
-__global__ __launch_bounds__(256) void k_nuts_tree_update(const double* Srho, const double* Sth, NutsVecs nv, int ld, int Q,
-                                                          int C, NutsChain nc, double* part, size_t pstride, int ldp)
+__global__ __launch_bounds__(256) void k_nuts_save_adj(NutsVecs nv, int ld, int Q, int C, NutsChain nc)
 {
     NUTS_IDX();
-    double acc[2][SB];
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
-        acc[0][u] = 0.0; acc[1][u] = 0.0;
+        const int s = s0 + u;
+        if (!fin || s >= S) continue;
+        const int ch = CM ? f : s;
+        if (!nc.active[ch]) continue;
+        const size_t off = f + (size_t)s * ld;
+        nv.Tadj[off] = nc.dir[ch] > 0 ? nv.RP[off] : nv.RM[off];
+    }
+}
+
+// a completed doubling (stored node of level j: rho, first-built momentum) joins the tree; the same three checks
+template <bool CM>
+__global__ __launch_bounds__(256) void k_nuts_tree_update(const double* Srho, const double* Spb, const double* Sth, NutsVecs nv,
+                                                          int ld, int Q, int C, NutsChain nc, double* part, size_t pstride,
+                                                          int ldp)
+{
+    NUTS_IDX();
+    double acc[6][SB];
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k][u] = 0.0;
         const int s = s0 + u;
         if (!fin || s >= S) continue;
         const int ch = CM ? f : s;
         if (!(nc.was[ch] && nc.valid[ch])) continue;
         const size_t off = f + (size_t)s * ld;
-        const double rho = nv.Trho[off] + Srho[off];
+        const double mi = nv.Mi[off];
+        const double rho_old = nv.Trho[off], rho_sub = Srho[off];
+        const double rho = rho_old + rho_sub;
         nv.Trho[off] = rho;
         if (nc.accsub[ch]) nv.Tth[off] = Sth[off];
-        const double mi = nv.Mi[off];
-        acc[0][u] = (mi * nv.RM[off]) * rho; acc[1][u] = (mi * nv.RP[off]) * rho;
+        const double rm = nv.RM[off], rp = nv.RP[off];
+        acc[0][u] = (mi * rm) * rho; acc[1][u] = (mi * rp) * rho;
+        const bool fwd = nc.dir[ch] > 0;
+        const double far_old = fwd ? rm : rp, new_edge = fwd ? rp : rm, pb = Spb[off], padj = nv.Tadj[off];
+        const double e1 = rho_old + pb;                            // the old tree + the subtree's first momentum
+        acc[2][u] = (mi * far_old) * e1; acc[3][u] = (mi * pb) * e1;
+        const double e2 = rho_sub + padj;                          // the subtree + the old tree's adjacent edge
+        acc[4][u] = (mi * padj) * e2; acc[5][u] = (mi * new_edge) * e2;
     }
-    nuts_store_partials<CM, 2>(acc, part, pstride, ldp, C);
+    nuts_store_partials<CM, 6>(acc, part, pstride, ldp, C);
 }
 
 template <bool CM>
@@ -374,10 +410,10 @@ __global__ __launch_bounds__(256) void k_nuts_merge_fin(const double* part, size
 {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int cc = c < C ? c : 0;
-    const double d1 = cm_sum_chunks(part, nchunk, ldp, cc);
-    const double d2 = cm_sum_chunks(part + pstride, nchunk, ldp, cc);
+    bool ok = true;
+    for (int k = 0; k < 6; ++k) ok = (cm_sum_chunks(part + k * pstride, nchunk, ldp, cc) > 0) && ok;
     if (threadIdx.x >= 64 || c >= C || !nc.active[c]) return;
-    if (!(d1 > 0 && d2 > 0)) { nc.valid[c] = 0; nc.active[c] = 0; }
+    if (!ok) { nc.valid[c] = 0; nc.active[c] = 0; }
 }
 
 __global__ __launch_bounds__(256) void k_nuts_end_doubling(int C, NutsChain nc, int j)
@@ -404,11 +440,11 @@ __global__ __launch_bounds__(256) void k_nuts_tree_fin(const double* part, size_
 {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int cc = c < C ? c : 0;
-    const double d1 = cm_sum_chunks(part, nchunk, ldp, cc);
-    const double d2 = cm_sum_chunks(part + pstride, nchunk, ldp, cc);
+    bool ok = true;
+    for (int k = 0; k < 6; ++k) ok = (cm_sum_chunks(part + k * pstride, nchunk, ldp, cc) > 0) && ok;
     if (threadIdx.x >= 64 || c >= C) return;
     if (!(nc.was[c] && nc.valid[c])) return;
-    if (!(d1 > 0 && d2 > 0)) nc.active[c] = 0;
+    if (!ok) nc.active[c] = 0;
     if (nc.depth[c] >= max_depth) { if (nc.active[c]) nc.nhit[c] += 1; nc.active[c] = 0; }
 }
 
@@ -516,7 +552,7 @@ __global__ void k_nuts_diag(NutsChain nc, int C, double* out)
 // ---- host -------------------------------------------------------------------------------------------------------
 struct NutsRun {
     Ctx& c; HmcState& h; NutsState& ns; NutsChain nc; NutsVecs nv;
-    double* Srho[NUTS_MAXD + 1]; double* Spb[NUTS_MAXD + 1]; double* Sth[NUTS_MAXD + 1];
+    double* Srho[NUTS_MAXD + 1]; double* Spb[NUTS_MAXD + 1]; double* Spe[NUTS_MAXD + 1]; double* Sth[NUTS_MAXD + 1];
     int C, Q, ld, nchunk, ldp; size_t pstride; double* part; dim3 vgrid; double var_par;
     uint64_t seed; uint32_t chain_offset, iter_idx;
     long long leapfrogs = 0;
@@ -589,18 +625,20 @@ struct NutsRun {
         for (int j = 0; j < max_depth; ++j) {
             MCML_TRY(pack(nact));
             hipLaunchKernelGGL(k_nuts_begin_doubling, dim3((C + 255) / 256), dim3(256), 0, c.stream, C, nc, 0);
+            if (h.cm) vec(k_nuts_save_adj<true>, nv, ld, Q, C, nc);
+            else vec(k_nuts_save_adj<false>, nv, ld, Q, C, nc);
             const int nleaf = 1 << j;
             for (int n = 0; n < nleaf; ++n) {
                 int tz = 0;
                 while ((n >> tz) & 1) ++tz;                            // merges this leaf completes
                 MCML_TRY(leaf(tz));
                 for (int l = 0; l < tz; ++l) {
-                    if (h.cm) vec(k_nuts_merge<true>, Srho[l], Spb[l], Sth[l], nv, nc.choose + (size_t)l * nc.Cp, ld, Q, C, nc, part, pstride, ldp);
-                    else vec(k_nuts_merge<false>, Srho[l], Spb[l], Sth[l], nv, nc.choose + (size_t)l * nc.Cp, ld, Q, C, nc, part, pstride, ldp);
+                    if (h.cm) vec(k_nuts_merge<true>, Srho[l], Spb[l], Spe[l], Sth[l], nv, nc.choose + (size_t)l * nc.Cp, ld, Q, C, nc, part, pstride, ldp);
+                    else vec(k_nuts_merge<false>, Srho[l], Spb[l], Spe[l], Sth[l], nv, nc.choose + (size_t)l * nc.Cp, ld, Q, C, nc, part, pstride, ldp);
                     hipLaunchKernelGGL(k_nuts_merge_fin, dim3((C + 63) / 64), dim3(256), 0, c.stream, part, pstride, nchunk, ldp, C, nc);
                 }
                 // push: the node under construction becomes the stored node of level tz (all growing chains agree)
-                std::swap(Srho[tz], nv.Crho); std::swap(Spb[tz], nv.Cpb); std::swap(Sth[tz], nv.Cth);
+                std::swap(Srho[tz], nv.Crho); std::swap(Spb[tz], nv.Cpb); std::swap(Spe[tz], nv.Cpe); std::swap(Sth[tz], nv.Cth);
                 MCML_HIP(hipGetLastError());
                 if ((n & 15) == 15 && n + 1 < nleaf) {                 // deep doublings: stop once every chain has, and
                     int na = 0;                                        // re-pack when a quarter of the packed chains
@@ -610,8 +648,8 @@ struct NutsRun {
                 }
             }
             hipLaunchKernelGGL(k_nuts_end_doubling, dim3((C + 255) / 256), dim3(256), 0, c.stream, C, nc, j);
-            if (h.cm) vec(k_nuts_tree_update<true>, Srho[j], Sth[j], nv, ld, Q, C, nc, part, pstride, ldp);
-            else vec(k_nuts_tree_update<false>, Srho[j], Sth[j], nv, ld, Q, C, nc, part, pstride, ldp);
+            if (h.cm) vec(k_nuts_tree_update<true>, Srho[j], Spb[j], Sth[j], nv, ld, Q, C, nc, part, pstride, ldp);
+            else vec(k_nuts_tree_update<false>, Srho[j], Spb[j], Sth[j], nv, ld, Q, C, nc, part, pstride, ldp);
             hipLaunchKernelGGL(k_nuts_tree_fin, dim3((C + 63) / 64), dim3(256), 0, c.stream, part, pstride, nchunk, ldp, C, nc, max_depth);
             MCML_HIP(hipGetLastError());
             int na = 0;
@@ -671,16 +709,17 @@ int nuts_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_nut
     MCML_TRY(hmc_alloc(c, C));
     ChainArrays ca = chain_arrays(h);
     NutsState& ns = c.nuts;
-    const int nvec = 14 + 3 * (max_depth + 1);
+    const int nvec = 16 + 4 * (max_depth + 1);
     const bool diag_metric = o->metric == 0;
     for (int i = 0; i < nvec; ++i) MCML_TRY(h.cm ? ns.vecs[i].alloc(C, Q) : ns.vecs[i].alloc(Q, C));
     MCML_TRY(ns.chain.ensure(nuts_chain_bytes(C)));
     NutsRun r{c, h, ns, nuts_chain(ns.chain.p, C), NutsVecs{}};
-    double* v[14];
-    for (int i = 0; i < 14; ++i) v[i] = ns.vecs[i].d();
-    r.nv = NutsVecs{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12], v[13]};
+    double* v[16];
+    for (int i = 0; i < 16; ++i) v[i] = ns.vecs[i].d();
+    r.nv = NutsVecs{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
     for (int l = 0; l <= max_depth; ++l) {
-        r.Srho[l] = ns.vecs[14 + 3 * l].d(); r.Spb[l] = ns.vecs[15 + 3 * l].d(); r.Sth[l] = ns.vecs[16 + 3 * l].d();
+        r.Srho[l] = ns.vecs[16 + 4 * l].d(); r.Spb[l] = ns.vecs[17 + 4 * l].d(); r.Spe[l] = ns.vecs[18 + 4 * l].d();
+        r.Sth[l] = ns.vecs[19 + 4 * l].d();
     }
     r.C = C; r.Q = Q; r.ld = h.V.ld; r.var_par = var_par; r.seed = seed; r.chain_offset = (uint32_t)o->chain_offset;
     r.iter_idx = iter_idx;
@@ -690,7 +729,7 @@ int nuts_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_nut
     r.nchunk = h.cm ? (int)r.vgrid.y : (int)r.vgrid.x;
     r.ldp = round_up(C, 64);
     r.pstride = (size_t)r.nchunk * r.ldp;
-    MCML_TRY(ns.part.ensure(sizeof(double) * 2 * r.pstride));
+    MCML_TRY(ns.part.ensure(sizeof(double) * 6 * r.pstride));
     r.part = ns.part.d();
     MCML_REQUIRE(h.V.ld == ns.vecs[0].ld, "nuts: state leading dimensions differ");
 

@@ -10,6 +10,8 @@ as the device code, one chain at a time in plain Python, so that tree depths, le
 accepted subtrees can be compared transition by transition.  Log density and gradient: oracle.log_prob / log_grad
 (mcmlmodel.h:138-153, 156-279).
 
+U-turn checks: around every merged subtree and, as base_nuts.hpp does since Stan 2.23, between its two halves; the same
+three checks for the whole tree after every doubling.
 Metric: diag_e with Stan's windowed adaptation (windowed_adaptation.hpp, var_adaptation.hpp, welford_var_estimator.hpp,
 adapt_diag_e_nuts.hpp), or unit_e.
 Streams (shared with csrc/nuts.h): initial state rng_normal(seed, q, chain, 0, 16 iter_idx + 0); momentum of transition
@@ -152,7 +154,8 @@ def nuts_chain(xb, ZL, y, var_par, fl, warmup, ndraw, seed, chain_id=0, iter_idx
         active = True
         for j in range(max_treedepth):
             d = 1 if gen.u() > 0.5 else -1
-            stack = {}                                            # level -> (rho, p_begin, proposal, lw)
+            padj = (rp if d > 0 else rm).copy()                   # the edge this doubling grows from, before it grows
+            stack = {}                                            # level -> (rho, p_first, p_last, proposal, lw)
             valid = True
             for n in range(1 << j):
                 tz = 0
@@ -172,36 +175,47 @@ def nuts_chain(xb, ZL, y, var_par, fl, warmup, ndraw, seed, chain_id=0, iter_idx
                 lw = H0 - h
                 choose = []
                 for l in range(tz):
-                    lwm = _logaddexp(stack[l][3], lw)
+                    lwm = _logaddexp(stack[l][4], lw)
                     choose.append(gen.u() < math.exp(lw - lwm))
                     lw = lwm
-                rho, pb, th = rn.copy(), mi * rn, x.copy()          # pb: M^-1 p of the first-built end
+                rho, pb, pe, th = rn.copy(), rn.copy(), rn.copy(), x.copy()   # a leaf: first- and last-built momentum
                 for l in range(tz):
-                    s_rho, s_pb, s_th, _ = stack[l]
-                    rho = s_rho + rho
-                    pb = s_pb
+                    l_rho, l_pb, l_pe, l_th, _ = stack[l]
+                    r_rho, r_pb, r_pe = rho, pb, pe
+                    rho = l_rho + r_rho
+                    pb = l_pb
                     if not choose[l]:
-                        th = s_th
-                    if not (float(np.dot(pb, rho)) > 0 and float(np.dot(mi * rn, rho)) > 0):
+                        th = l_th
+                    e1 = l_rho + r_pb                              # between the subtrees (base_nuts.hpp since 2.23)
+                    e2 = r_rho + l_pe
+                    dots = (np.dot(mi * l_pb, rho), np.dot(mi * r_pe, rho), np.dot(mi * l_pb, e1), np.dot(mi * r_pb, e1),
+                            np.dot(mi * l_pe, e2), np.dot(mi * r_pe, e2))
+                    if not all(float(v) > 0 for v in dots):
                         valid = False
                         break
                 if not valid:
                     break
-                stack[tz] = (rho, pb, th, lw)
+                stack[tz] = (rho, pb, pe, th, lw)
             if not valid:
                 active = False
                 break
             depth = j + 1
-            s_rho, _, s_th, lws = stack[j]
+            s_rho, s_pb, _, s_th, lws = stack[j]
             if lws > lw_tree:
                 acc = True
             else:
                 acc = gen.u() < math.exp(lws - lw_tree)
             lw_tree = _logaddexp(lw_tree, lws)
-            t_rho = t_rho + s_rho
+            rho_old = t_rho
+            t_rho = rho_old + s_rho
             if acc:
                 t_th = s_th
-            if not (float(np.dot(mi * rm, t_rho)) > 0 and float(np.dot(mi * rp, t_rho)) > 0):
+            far_old, new_edge = (rm, rp) if d > 0 else (rp, rm)
+            e1 = rho_old + s_pb
+            e2 = s_rho + padj
+            dots = (np.dot(mi * rm, t_rho), np.dot(mi * rp, t_rho), np.dot(mi * far_old, e1), np.dot(mi * s_pb, e1),
+                    np.dot(mi * padj, e2), np.dot(mi * new_edge, e2))
+            if not all(float(v) > 0 for v in dots):
                 active = False
                 break
             if depth >= max_treedepth:

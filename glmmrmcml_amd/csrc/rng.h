@@ -147,6 +147,15 @@ __host__ __device__ static inline double rng_normal(uint64_t seed, uint32_t elem
     return rng_ppnd16(rng_u52(o[0], o[1]));
 }
 
+// uniform on (0, 1) with the same addressing (the No-U-Turn sampler's initial values, nuts.h)
+__host__ __device__ static inline double rng_uniform(uint64_t seed, uint32_t elem, uint32_t chain,
+                                                     uint32_t prop, uint32_t tag)
+{
+    uint32_t o[4];
+    philox4x32_10(elem, chain, prop, tag, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    return rng_u52(o[0], o[1]);
+}
+
 // std::minstd_rand (mhmcmc.h:27)
 __host__ __device__ static inline uint32_t minstd_next(uint32_t& x)
 {

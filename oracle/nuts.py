@@ -14,7 +14,7 @@ U-turn checks: around every merged subtree and, as base_nuts.hpp does since Stan
 three checks for the whole tree after every doubling.
 Metric: diag_e with Stan's windowed adaptation (windowed_adaptation.hpp, var_adaptation.hpp, welford_var_estimator.hpp,
 adapt_diag_e_nuts.hpp), or unit_e.
-Streams (shared with csrc/nuts.h): initial state rng_normal(seed, q, chain, 0, 16 iter_idx + 0); momentum of transition
+Streams (shared with csrc/nuts.h): initial state 4 u - 2 with u = rng_uniform(seed, q, chain, 0, 16 iter_idx + 6); momentum of transition
 `it` tag 16 iter_idx + 4 (divided by sqrt of the inverse metric); momentum of round r of the k-th step-size search tag
 16 iter_idx + 5 with prop = 1000 k + r; uniforms from the
 chain's minstd stream in the order: direction of a doubling; one draw per merge of a leaf (levels ascending); one
@@ -90,7 +90,14 @@ def nuts_chain(xb, ZL, y, var_par, fl, warmup, ndraw, seed, chain_id=0, iter_idx
     normal = lambda prop, tag: np.array([orc.normal(seed, q, chain_id, prop, tag) for q in range(Q)])
     gen = _Stream(seed, chain_id, iter_idx)
 
-    theta = normal(0, 16 * iter_idx + 0)
+    def uniform(prop, tag):                                       # csrc/rng.h::rng_uniform
+        out = np.empty(Q)
+        for q in range(Q):
+            o = orc.philox((q, chain_id, prop, tag), (seed & 0xffffffff, (seed >> 32) & 0xffffffff))
+            out[q] = ((o[0] >> 6) * 67108864.0 + (o[1] >> 6) + 0.5) * (1.0 / 4503599627370496.0)
+        return out
+
+    theta = 4.0 * uniform(0, 16 * iter_idx + 6) - 2.0              # Stan's default initial values: uniform(-2, 2)
     eps = float(stepsize)
     mi = np.ones(Q)                                               # inverse metric (diag_e starts from ones)
 

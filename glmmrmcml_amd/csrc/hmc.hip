@@ -464,7 +464,7 @@ template <class Epi>
 static int hmc_forward_launch(Ctx& c, const double* X, int ldx, const Epi& epi)
 {
     HmcState& h = c.hmc;
-    // at most 4 chains (chains = 1: the reference's layout; the tail of a NUTS doubling): an HBM-bound stream, not an MFMA tile
+    // at most 16 chains (chains = 1: the reference's layout; the tail of a NUTS doubling): an HBM-bound stream, not an MFMA tile
     if (use_skinny() && skinny_applicable(c.plan_fwd, c.n, c.Q, h.Cw, c.ZL.ld))
         return launch_skinny(c.stream, c.plan_fwd, h.Cw, c.ZL.d(), c.ZL.ld, X, ldx, epi);
     if (c.band_fwd && dlds_applicable(c.n, h.Cw, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))

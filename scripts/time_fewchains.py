@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 d = synth.geospatial(n, seed=1)
 ctx = api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"])
 ctx.update_L(d["theta"])
-for C in (1, 2, 4, 5):
+for C in (1, 4, 8, 12, 16, 17):
     for sk in ("1", "0"):
         os.environ["GLMMR_MCML_SKINNY"] = sk
         ctx.hmc_sample(d["beta"], d["sigma"], 5, C, 5.0, 10, 0.9, seed=1, chains=C)

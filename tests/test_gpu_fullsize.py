@@ -150,9 +150,9 @@ def test_longitudinal_poisson_reduced(orc):
     assert np.abs(H - Ho).max() < 1e-4 * np.abs(Ho).max()
 
 
-@pytest.mark.parametrize("chains", [1, 4])
+@pytest.mark.parametrize("chains", [1, 4, 11])
 def test_streamed_and_mfma_products_agree_at_full_size(monkeypatch, chains):
-    """n = Q = 5000, <= 4 chains: the streamed products (dgemm_skinny.h: 20 row blocks, 40 K chunks, the zero K ranges
+    """n = Q = 5000, <= 16 chains: the streamed products (dgemm_skinny.h: 40 row blocks, 40 K chunks, the zero K ranges
     of the triangular ZL never launched into) against the 128-column MFMA tiles on the same chains -- identical
     accept/reject decisions, samples to rounding (chains = 1 is the reference's layout, Q x (m + 1))"""
     from glmmrmcml_amd import api
@@ -169,7 +169,7 @@ def test_streamed_and_mfma_products_agree_at_full_size(monkeypatch, chains):
                                                 want_trace=True)
             out[mode] = (ctx.get_u(), flags.copy(), probs.copy())
     monkeypatch.delenv("GLMMR_MCML_SKINNY", raising=False)
-    assert out["skinny"][0].shape == (5000, 5 if chains == 1 else 16)
+    assert out["skinny"][0].shape == (5000, 5 if chains == 1 else 4 * chains)
     assert np.array_equal(out["skinny"][1], out["mfma"][1])
     assert np.abs(out["skinny"][2] - out["mfma"][2]).max() < 1e-9
     assert np.abs(out["skinny"][0] - out["mfma"][0]).max() < 1e-8 * np.abs(out["mfma"][0]).max()

@@ -48,8 +48,8 @@ CASES = [(synth.geospatial, dict(n=96), 0.9), (synth.geospatial, dict(n=333), 1.
 
 @pytest.fixture(params=["skinny", "mfma"])
 def few_chain_path(request, monkeypatch):
-    """at most 4 chains run the streamed products of dgemm_skinny.h unless GLMMR_MCML_SKINNY=0: the few-chain parity
-    tests run with both settings (5 chains / columns take the MFMA kernels either way, 1 chain switches)"""
+    """at most 16 chains run the streamed products of dgemm_skinny.h unless GLMMR_MCML_SKINNY=0: the few-chain parity
+    tests run with both settings, so the MFMA kernels and their fused epilogues keep their chain-by-chain check"""
     if request.param == "mfma":
         monkeypatch.setenv("GLMMR_MCML_SKINNY", "0")
     else:
@@ -63,7 +63,7 @@ def test_log_prob_and_log_grad(orc, gen, kw, vp, few_chain_path):
     d = gen(**kw)
     ctx, ZL, xb, fl, _ = _setup(orc, d, api)
     rng = np.random.default_rng(3)
-    ncol = 3 if few_chain_path == "skinny" else 5          # <= 4 columns: the streamed products
+    ncol = 3 if few_chain_path == "skinny" else 5          # 3: the 4-wide instantiation of the streamed products
     V = rng.normal(size=(d["Q"], ncol)) * 0.7
     lp, G = ctx.log_prob_grad(d["beta"], vp, V)
     for c in range(ncol):
@@ -81,7 +81,7 @@ def test_chains_match_oracle_chain_by_chain(orc, gen, kw, vp, few_chain_path):
     ctx, ZL, xb, fl, Lo = _setup(orc, d, api)
     Cn, warm, nsamp, lam, ms, ta, seed, it = 5, 14, 15, 0.4, 6, 0.9, 20240601, 2
     if few_chain_path == "skinny":
-        Cn = 3                                                 # <= 4 chains: the streamed products
+        Cn = 3                                                 # the 4-wide instantiation of the streamed products
     diag, flags, probs = ctx.hmc_sample(d["beta"], vp, warm, nsamp, lam, ms, ta, seed, chains=Cn,
                                         chain_offset=10, iter_idx=it, adapt=10, want_trace=True)
     u = ctx.get_u()

@@ -116,3 +116,26 @@ def test_sharded_chains_equal_unsharded_chains():
     # run the MFMA tiles: equal to rounding, not bit for bit
     assert np.abs(u[:, :4] - out["lo"][0]).max() < 1e-8 * max(1.0, np.abs(u).max())
     assert np.abs(u[:, 4:] - out["hi"][0]).max() < 1e-8 * max(1.0, np.abs(u).max())
+
+
+def test_full_size_run_hits_the_gaussian_posterior():
+    """config 2's size (n = Q = 2000, 256 chains): 40 adaptive transitions with every mechanism in play -- metric
+    window, re-searched step size, packing of the chains that still grow down to the streamed products -- then the
+    closed-form posterior mean of u = L gamma as in the fixed-length sampler's full-size test"""
+    from glmmrmcml_amd import api
+    n, chains = 2000, 256
+    d = synth.geospatial(n)
+    with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"]) as ctx:
+        ctx.update_L(d["theta"])
+        diag, tr = ctx.nuts_sample(d["beta"], d["sigma"], 40, chains, seed=3, chains=chains, want_trace=True)
+        u = ctx.get_u()
+        L = ctx.gen_D(d["theta"], chol=True)
+    assert u.shape == (n, chains) and np.isfinite(u).all()
+    assert tr["depth"][:, -1].min() >= 1 and tr["depth"].max() <= 10 and (tr["nleap"] <= 1023).all()
+    assert 0.5 < tr["accept"][:, 30:].mean() <= 1.0
+    s2 = d["sigma"] ** 2
+    S = np.linalg.inv(np.eye(n) + L.T @ L / s2)
+    mu_u = L @ (S @ (L.T @ (d["y"] - d["X"] @ d["beta"]))) / s2
+    sd_u = np.sqrt(np.einsum("ij,jk,ik->i", L, S, L) / chains)
+    err = u.mean(1) - mu_u
+    assert np.mean(np.abs(err) < 6 * sd_u + 0.1 * np.abs(mu_u).max()) > 0.99

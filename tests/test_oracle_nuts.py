@@ -35,3 +35,28 @@ def test_oracle_nuts_is_deterministic_and_keyed_by_chain(orc):
     c = nuts.nuts_chain(xb, ZL, d["y"], 1.0, fl, 10, 5, seed=7, chain_id=3, max_treedepth=5)
     assert np.array_equal(a[0], b[0]) and not np.array_equal(a[0], c[0])
     assert a[1]["depth"].max() <= 5 and (a[1]["nleap"] <= 2 ** 5 - 1).all()
+
+
+def test_adaptation_windows_follow_stans_documented_schedule():
+    """Stan reference manual, "Automatic parameter tuning": with 1000 warm-up iterations the fast / slow / fast schedule is
+    75 | 25, 50, 100, 200, 500 | 50 -- the slow windows (where the metric is estimated) end after iterations 100, 150,
+    250, 450 and 950; the last one is stretched to reach the terminal buffer.  With fewer than 20 warm-up iterations
+    there is no slow window; with 100 (gen_u_samples' default) the buffers are rescaled to 15 | 75 | 10."""
+    from oracle.nuts import _Windows
+
+    def ends(W):
+        w, out, n = _Windows(W), [], 0
+        for it in range(W):
+            if w.in_window():
+                n += 1
+            if w.at_end():
+                w.compute_next()
+                out.append((it + 1, n))
+                n = 0
+            w.counter += 1
+        return out
+
+    assert ends(1000) == [(100, 25), (150, 50), (250, 100), (450, 200), (950, 500)]
+    assert ends(100) == [(90, 75)]
+    assert ends(19) == [] and ends(14) == []
+    assert ends(24) == [(22, 19)]

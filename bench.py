@@ -16,6 +16,11 @@ workload (every N): BASELINE config 3 as written -- Gaussian geospatial, n = Q =
          rank of the 8-GPU job runs).
          --dense-z replaces Z = I by a dense orthogonal-like Z (ZL dense: no zero
          skipping) -- a second, clearly labelled workload, not the metric's.
+         --as-rank-of N (with --gpus 1): what ONE rank of the N-GPU job executes, on one GPU:
+         1024 / N chains, the theta-step sharded over candidate thetas with this rank's share
+         of every round, the peers emulated as copies of this rank (their candidate values
+         come from an untimed recording run of the same iterations; include/glmmr_mcml_c.h
+         glmmr_mcml_dbg_emulate_world).  The time of the collectives themselves is NOT in it.
 Inputs are resident in HBM before the timed region starts.
 
 Launch: python bench.py --gpus 1 --steps K --warmup W      (single GPU)
@@ -102,6 +107,7 @@ def main():
     ap.add_argument("--reduce", choices=("native", "torch"), default="native",
                     help="N > 1: the library's own RCCL communicator (default) or the torch.distributed hook")
     ap.add_argument("--dense-z", action="store_true", help="dense (non-identity) Z: ZL dense, no zero skipping")
+    ap.add_argument("--as-rank-of", type=int, default=0, help="time one rank of an N-rank job on one GPU (peers emulated)")
     args = ap.parse_args()
 
     import torch
@@ -134,6 +140,12 @@ def main():
             hook = gdist.make_reduce_hook()
 
     cfg = dict(CFG); cfg["n"] = args.n
+    emu = args.as_rank_of if args.as_rank_of > 1 else 0
+    if emu:
+        assert world == 1, "--as-rank-of emulates the peers on ONE GPU: launch it with --gpus 1"
+        assert CFG["chains_total"] % emu == 0
+        if args.chains <= 0:
+            args.chains = CFG["chains_total"] // emu
     if args.chains > 0:
         cfg["chains_per_gpu"] = args.chains
     elif args.weak:
@@ -185,8 +197,14 @@ def main():
             tdist.barrier()
             torch.cuda.synchronize()
 
-    if args.warmup > 0:
+    if emu:
+        # recording run: the very iterations that are timed below, every rank's candidate thetas evaluated here
+        ctx.emulate_world(emu, 1)
+        run(args.steps)
+        ctx.emulate_world(emu, 2)
+    elif args.warmup > 0:
         run(args.warmup)
+    shard0 = ctx.shard_stats()
     ctx.profile(enable=True, reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -198,6 +216,8 @@ def main():
         tdist.all_reduce(tt, op=tdist.ReduceOp.MAX)
         dt = float(tt.item())
     prof = ctx.profile(enable=False)
+    shard1 = ctx.shard_stats()
+    shard = {k: shard1[k] - shard0[k] for k in shard1}
     assert res["iters"] == args.steps, "timed region ran %d iterations, not %d" % (res["iters"], args.steps)
 
     if rank == 0:
@@ -236,6 +256,11 @@ def main():
                                       cfg["hmc_warmup"], cfg["max_steps"], cfg["theta_maxfun"]),
                        "n": n, "Q": n, "m_per_gpu": C, "m_total": C * world, "parallelism": "chains x%d" % world,
                        "collective": collective,
+                       "theta_step": ("sharded over candidate thetas: %d rounds, %d evaluations on this rank of %d in all, "
+                                      "%d all-gather(s) of the samples (%.1f MB each)"
+                                      % (shard["theta_rounds"], shard["theta_evals_own"], shard["theta_evals_all"],
+                                         shard["gathers"], 8e-6 * shard["gather_doubles"] / max(1, shard["gathers"])))
+                                     if shard["theta_rounds"] else "sequential BOBYQA on this GPU, %d evaluations per step" % cfg["theta_maxfun"],
                        "accept_rate": res["accept_rate"], "leapfrog_steps_last_iter": res["leapfrog_total"]},
             "roofline": {"bound": "mfma",
                          "kernel": "dgemm_%s_kernel (HMC forward / backward n x Q x C product, FP64 MFMA)"
@@ -252,7 +277,15 @@ def main():
                                  "prices the same launches at SURVEY 8(d)'s dense 2nQC",
                          "gemm_share_of_step": avg_s * (prof["fwd_n_all"] + prof["bwd_n_all"]) / dt},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if emu:
+            line["config"]["as_rank_of"] = emu
+            line["config"]["note"] = ("ONE rank of the %d-GPU strong-scaling job timed on one GPU: %d of the 1024 chains, this rank's "
+                                      "share of every theta-step round; peers emulated as copies of this rank, the collectives' own "
+                                      "time (1 all-gather of 41 MB + ~%d small all-reduces per step over xGMI) is not included. "
+                                      "value = this rank's chains / its step time; x%d = the job's rate if every rank takes this long"
+                                      % (emu, C, 1 + shard["theta_rounds"] // max(1, args.steps), emu))
+            line["config"]["projected_job_value"] = args.steps * C * emu / dt
+        if world == 1 and not args.no_cpu_baseline and not emu:
             try:
                 cfg["chains_total_run"] = C * world; cfg["dense_z"] = bool(args.dense_z)
                 line["cpu_baseline"] = cpu_baseline(d, cfg)

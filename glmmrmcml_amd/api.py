@@ -36,7 +36,8 @@ class HmcOpts(C.Structure):
 
 
 class Ext(C.Structure):
-    _fields_ = [("seed", C.c_uint64), ("chains", C.c_int), ("maxfun", C.c_int), ("device", C.c_int)]
+    _fields_ = [("seed", C.c_uint64), ("chains", C.c_int), ("maxfun", C.c_int), ("device", C.c_int),
+                ("theta_batch", C.c_int)]
 
 
 class HmcDiag(C.Structure):
@@ -103,6 +104,7 @@ class Context:
         self._reduce_cb = REDUCE_FN(reduce) if reduce is not None else REDUCE_FN()
         o.reduce = self._reduce_cb
         self._h = C.c_void_p()
+        self._world = int(world)
         _lib.check(L.glmmr_mcml_ctx_create(C.byref(p), C.byref(o), C.byref(self._h)))
         self.family, self.link = family, link
         if Z is None:
@@ -130,6 +132,7 @@ class Context:
     def comm_init_rccl(self, unique_id, rank, world):
         buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
         _lib.check(_lib.lib().glmmr_mcml_ctx_comm_init_rccl(self._h, buf, int(rank), int(world)))
+        self._world = int(world)
 
     def comm_allreduce(self, vals):
         """sum over the ranks through the path the statistics take (self-test of the exchange)"""
@@ -155,6 +158,27 @@ class Context:
         u = np.zeros((self.Q, self.mcols), order="F")
         _lib.check(_lib.lib().glmmr_mcml_get_u(self._h, _p(u), self.Q))
         return u
+
+    def get_u_all(self, world=None):
+        """every rank's samples, rank r's columns at r * mcols: the u mcml_full returns (mcml_full.cpp:144-145).
+        Collective unless called right after mcml_full / mcml_optim (the theta-step has gathered them)."""
+        w = int(world) if world else max(1, int(getattr(self, "_world", 1)))
+        u = np.zeros((self.Q, self.mcols * w), order="F")
+        nc = C.c_int()
+        _lib.check(_lib.lib().glmmr_mcml_get_u_all(self._h, _p(u), self.Q, C.byref(nc)))
+        assert nc.value == u.shape[1], (nc.value, u.shape)
+        return u
+
+    def shard_stats(self):
+        out = (C.c_longlong * 6)()
+        _lib.check(_lib.lib().glmmr_mcml_ctx_shard_stats(self._h, out))
+        return dict(gathers=out[0], gather_doubles=out[1], theta_rounds=out[2], theta_evals_own=out[3],
+                    theta_evals_all=out[4])
+
+    def emulate_world(self, world, mode):
+        """bench.py --as-rank-of N (include/glmmr_mcml_c.h glmmr_mcml_dbg_emulate_world): 1 record, 2 replay"""
+        _lib.check(_lib.lib().glmmr_mcml_dbg_emulate_world(self._h, int(world), int(mode)))
+        self._world = int(world) if world and world > 1 else 1
 
     # -- A8
     def mvn_ll(self, theta):
@@ -251,16 +275,16 @@ class Context:
         return (diag, tr) if want_trace else diag
 
     # -- drivers on the resident context
-    def _ext(self, seed, chains, maxfun):
-        return Ext(int(seed or 0), int(chains or 1), int(maxfun or 0), 0)
+    def _ext(self, seed, chains, maxfun, theta_batch=0):
+        return Ext(int(seed or 0), int(chains or 1), int(maxfun or 0), 0, int(theta_batch or 0))
 
     def npar(self):
         return _lib.lib().glmmr_mcml_ctx_npar(self._h)
 
-    def mcml_optim(self, start, trace=0, mcnr=False, maxfun=0):
+    def mcml_optim(self, start, trace=0, mcnr=False, maxfun=0, theta_batch=0):
         start = _f(start).ravel(); R = self.npar()
         b = np.zeros(self.P); t = np.zeros(R); sg = C.c_double()
-        e = self._ext(0, 1, maxfun)
+        e = self._ext(0, 1, maxfun, theta_batch)
         _lib.check(_lib.lib().glmmr_mcml_ctx_optim(self._h, _p(start), start.size, int(trace), int(mcnr),
                                                    C.byref(e), _p(b), _p(t), C.byref(sg)))
         return dict(beta=b, theta=t, sigma=sg.value)
@@ -287,11 +311,11 @@ class Context:
 
     def mcml_full(self, start, mcnr=False, m=500, maxiter=30, warmup=500, tol=1e-3, verbose=False,
                   lambda_=0.05, trace=0, refresh=500, maxsteps=100, target_accept=0.9, seed=0, chains=1,
-                  maxfun=0):
+                  maxfun=0, theta_batch=0):
         start = _f(start).ravel(); R = self.npar()
         b = np.zeros(self.P); t = np.zeros(R); sg = C.c_double(); conv = C.c_int(); it = C.c_int()
         d = HmcDiag()
-        e = self._ext(seed, chains, maxfun)
+        e = self._ext(seed, chains, maxfun, theta_batch)
         _lib.check(_lib.lib().glmmr_mcml_ctx_full(
             self._h, _p(start), start.size, int(mcnr), int(m), int(maxiter), int(warmup), C.c_double(tol),
             int(verbose), C.c_double(lambda_), int(trace), int(refresh), int(maxsteps), C.c_double(target_accept),
@@ -365,7 +389,7 @@ def mcml_full(cov, data, eff_range, Z, X, y, family, link, start, mcnr=False, m=
     R = int(start.size - p.P - 1)
     b = np.zeros(p.P); t = np.zeros(R); sg = C.c_double(); conv = C.c_int(); uc = C.c_int()
     u = np.zeros((p.Q, ncol), order="F")
-    e = Ext(int(seed), int(chains), int(maxfun), 0)
+    e = Ext(int(seed), int(chains), int(maxfun), 0, 0)
     _lib.check(L.glmmr_mcml_full(C.byref(p), _p(start), start.size, int(mcnr), int(m), int(maxiter), int(warmup),
                                  C.c_double(tol), int(verbose), C.c_double(lambda_), int(trace), int(refresh),
                                  int(maxsteps), C.c_double(target_accept), C.byref(e), _p(b), _p(t), C.byref(sg),
@@ -378,7 +402,7 @@ def _la_call(fn, cov, data, eff_range, Z, X, y, family, link, start, usehess, to
     start = _f(start).ravel()
     R = int(start.size - p.P - 1)
     b = np.zeros(p.P); t = np.zeros(R); sg = C.c_double(); se = np.zeros(start.size); u = np.zeros(p.Q)
-    e = Ext(0, 1, int(maxfun), 0)
+    e = Ext(0, 1, int(maxfun), 0, 0)
     _lib.check(fn(C.byref(p), _p(start), start.size, int(usehess), C.c_double(tol), int(verbose), int(trace),
                   int(maxiter), C.byref(e), _p(b), _p(t), C.byref(sg), _p(se), _p(u)))
     return dict(beta=b, theta=t, sigma=sg.value, se=se, u=u.reshape(-1, 1))
@@ -406,7 +430,7 @@ def mcmc_sample(Z, L, X, y, beta, family, link, warmup, nsamp, lambda_, var_par=
     lib = _lib.lib()
     ncol = lib.glmmr_mcml_sample_cols(int(nsamp), int(chains))
     out = np.zeros((Q, ncol), order="F"); nc = C.c_int()
-    e = Ext(int(seed), int(chains), 0, 0)
+    e = Ext(int(seed), int(chains), 0, 0, 0)
     _lib.check(lib.glmmr_mcml_mcmc_sample(_p(Z), _p(Lm), _p(X), _p(y), n, Q, X.shape[1], _p(beta),
                                           family.encode(), link.encode(), int(warmup), int(nsamp),
                                           C.c_double(lambda_), C.c_double(var_par), int(trace), int(refresh),
@@ -423,7 +447,7 @@ def gen_u_samples(y, X, Z, L, beta, family, link, sigma=1.0, warmup_iter=100, m=
     n, Q = Z.shape
     ncol = chains * -(-int(m) // chains)
     out = np.zeros((Q, ncol), order="F"); nc = C.c_int()
-    e = Ext(int(seed), int(chains), 0, 0)
+    e = Ext(int(seed), int(chains), 0, 0, 0)
     o = NutsOpts(int(warmup_iter), int(m), int(max_treedepth), float(adapt_delta), 0.0, int(chains), 0, 0)
     _lib.check(_lib.lib().glmmr_mcml_gen_u_samples(_p(Z), _p(Lm), _p(X), _p(y), n, Q, X.shape[1], _p(beta), family.encode(),
                                                    link.encode(), C.c_double(sigma), int(warmup_iter), int(m), C.byref(o),
@@ -436,7 +460,7 @@ def _fit_call(fn, prob_args, u, start, extra, sparse=None, maxfun=0):
     u = _f(u); start = _f(start).ravel()
     R = int(start.size - p.P - 1) if start.size > p.P + 1 else 0
     b = np.zeros(p.P); t = np.zeros(max(R, 64)); sg = C.c_double()
-    e = Ext(0, 1, int(maxfun), 0)
+    e = Ext(0, 1, int(maxfun), 0, 0)
     args = [C.byref(p)]
     if sparse is not None:
         Ap, Ai = _i(sparse[0]).ravel(), _i(sparse[1]).ravel()
@@ -480,7 +504,7 @@ def mcml_optim_sparse(cov, data, eff_range, Ap, Ai, Z, X, y, u, family, link, st
     Lp = np.zeros(p.Q + 1, dtype=np.int32); Li = np.zeros(max(cap, 1), dtype=np.int32)
     Lx = np.zeros(max(cap, 1)); D = np.zeros(p.Q)
     Ap_, Ai_ = _i(Ap).ravel(), _i(Ai).ravel()
-    e = Ext(0, 1, int(maxfun), 0)
+    e = Ext(0, 1, int(maxfun), 0, 0)
     _lib.check(lib.glmmr_mcml_optim_sparse(C.byref(p), Ap_.ctypes.data_as(c_ip), Ai_.ctypes.data_as(c_ip), Ai_.size,
                                            _p(u), u.shape[1], _p(start), start.size, int(trace), int(mcnr),
                                            C.byref(e), _p(b), _p(t), C.byref(sg), Lp.ctypes.data_as(c_ip),
@@ -501,7 +525,7 @@ def mcml_hess(cov, data, eff_range, Z, X, y, u, family, link, start, tol=1e-5, t
     u = _f(u); start = _f(start).ravel()
     nv = p.P + _npar_of(cov)
     H = np.zeros((nv, nv), order="F")
-    e = Ext(0, 1, 0, 0)
+    e = Ext(0, 1, 0, 0, 0)
     if sparse is None:
         _lib.check(_lib.lib().glmmr_mcml_hess(C.byref(p), _p(u), u.shape[1], _p(start), start.size,
                                               C.c_double(tol), int(trace), C.byref(e), _p(H)))
@@ -521,7 +545,7 @@ def aic_mcml(cov, data, eff_range, Z, X, y, u, family, link, beta_par, cov_par):
     """aic_mcml(...) -> double   (src/mcml_optim.cpp:356-392)"""
     p, keep = _problem(cov, data, eff_range, Z, X, y, family, link)
     u = _f(u); bp = _f(beta_par).ravel(); cp = _f(cov_par).ravel()
-    out = C.c_double(); e = Ext(0, 1, 0, 0)
+    out = C.c_double(); e = Ext(0, 1, 0, 0, 0)
     _lib.check(_lib.lib().glmmr_mcml_aic(C.byref(p), _p(u), u.shape[1], _p(bp), bp.size, _p(cp), cp.size,
                                          C.byref(e), C.byref(out)))
     return out.value

@@ -125,7 +125,7 @@ extern "C" int glmmr_mcml_set_u(glmmr_mcml_ctx* h, const double* u, int Q, int n
     MCML_TRY(upload_matrix(c.U, u, Q, ncols, Q, c.stream));
     c.mcols = ncols; c.niter = niter;
     c.m_global = ncols; c.niter_global = niter;
-    c.zu_valid = false;
+    c.zu_valid = false; c.uall_valid = false;
     return c.sync();
 }
 
@@ -136,6 +136,43 @@ extern "C" int glmmr_mcml_get_u(glmmr_mcml_ctx* h, double* u, int ldu)
     MCML_REQUIRE(c.mcols > 0 && ldu >= c.Q, "get_u: no samples / bad ldu");
     MCML_HIP(hipSetDevice(c.device));
     return download_matrix(u, ldu, c.U.d(), c.U.ld, c.Q, c.mcols, c.stream);
+}
+
+extern "C" int glmmr_mcml_get_u_all(glmmr_mcml_ctx* h, double* u, int ldu, int* ncols_out)
+{
+    MCML_REQUIRE(h && u, "get_u_all: null argument");
+    Ctx& c = h->c;
+    MCML_REQUIRE(c.mcols > 0 && ldu >= c.Q, "get_u_all: no samples / bad ldu");
+    MCML_HIP(hipSetDevice(c.device));
+    if (comm_world(c) <= 1) {
+        if (ncols_out) *ncols_out = c.mcols;
+        return download_matrix(u, ldu, c.U.d(), c.U.ld, c.Q, c.mcols, c.stream);
+    }
+    MCML_TRY(gather_samples(c));
+    if (ncols_out) *ncols_out = c.Uall.cols;
+    return download_matrix(u, ldu, c.Uall.d(), c.Uall.ld, c.Q, c.Uall.cols, c.stream);
+}
+
+extern "C" int glmmr_mcml_ctx_shard_stats(glmmr_mcml_ctx* h, long long* out6)
+{
+    MCML_REQUIRE(h && out6, "shard_stats: null argument");
+    const Ctx& c = h->c;
+    out6[0] = c.gather_calls; out6[1] = c.gather_doubles; out6[2] = c.theta_rounds; out6[3] = c.theta_evals_own;
+    out6[4] = c.theta_evals_all; out6[5] = 0;
+    return MCML_OK;
+}
+
+extern "C" int glmmr_mcml_dbg_emulate_world(glmmr_mcml_ctx* h, int world, int mode)
+{
+    MCML_REQUIRE(h, "emulate_world: null context");
+    Ctx& c = h->c;
+    MCML_REQUIRE(c.world <= 1 && !c.comm, "emulate_world: the context is rank %d of a real group of %d", c.rank, c.world);
+    MCML_REQUIRE(world <= 1 || mode == 1 || mode == 2, "emulate_world: mode must be 1 (record) or 2 (replay)");
+    if (world <= 1) { c.emu_world = 0; c.emu_mode = 0; c.emu_trace.clear(); c.emu_pos = 0; c.uall_valid = false; return MCML_OK; }
+    if (c.emu_world != world) { c.emu_trace.clear(); c.uall_valid = false; }
+    c.emu_world = world; c.emu_mode = mode; c.emu_pos = 0;
+    if (mode == 1) c.emu_trace.clear();
+    return MCML_OK;
 }
 
 extern "C" int glmmr_mcml_ctx_mvn_ll(glmmr_mcml_ctx* h, const double* theta, double* out)

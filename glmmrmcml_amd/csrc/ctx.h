@@ -160,6 +160,18 @@ struct Ctx {
     void* reduce_user = nullptr;
     void* comm = nullptr;       // ncclComm_t of the native RCCL path (comm.hip); null = hook or single process
     long long coll_calls = 0, coll_doubles = 0;   // collectives issued / doubles summed (tests, bench)
+    long long gather_calls = 0, gather_doubles = 0;   // all-gathers issued / doubles received
+    // every rank's sample columns (comm.hip allgather_dev): rank r's mcols columns at column r * mcols.  Valid until the
+    // samples change.  The theta-step of a sharded job reads these (drivers.hip::d_optim).
+    DevMat Uall;
+    bool uall_valid = false;
+    long long theta_rounds = 0, theta_evals_own = 0, theta_evals_all = 0;   // sharded theta-step: exchanges, evaluations here / everywhere
+    // rank emulation on one GPU (bench.py --as-rank-of N, include/glmmr_mcml_c.h glmmr_mcml_dbg_emulate_world): the
+    // other ranks are copies of this one -- a sum is `emu_world` times the local value, a gather `emu_world` copies of
+    // the local block; the candidate thetas of the other ranks are evaluated here too (mode 1, values recorded) or taken
+    // from that record (mode 2: only this rank's share runs, which is what a rank of the real job executes)
+    int emu_world = 0, emu_mode = 0;
+    std::vector<std::vector<double>> emu_trace; size_t emu_pos = 0;
     DevBuf reduce_buf;          // doubles handed to the collective
     DevBuf scratch;             // short-lived per-call scratch
 
@@ -191,12 +203,17 @@ struct Ctx {
 // ---- comm.hip ----
 void comm_release(Ctx& c);
 int allreduce_dev(Ctx& c, double* dev, int n);              // in place on device memory, on c.stream
+int allgather_dev(Ctx& c, const double* send, double* recv, size_t count);
+int gather_samples(Ctx& c);                                  // c.Uall <- all ranks' sample columns
+inline int comm_world(const Ctx& c) { return c.emu_world > 1 ? c.emu_world : c.world; }
 inline void Ctx::comm_release_hook() { comm_release(*this); }
 
 // ---- mvn.hip ----
 int mvn_setup(Ctx& c);
-// sum over the locally held columns of sum_b log N(u_b; 0, D_b(theta)); *ncols = local columns
+// sum over the locally held columns of sum_b log N(u_b; 0, D_b(theta))
 int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out);
+// the same over the m columns of any resident sample matrix (Q x m, leading dimension ldu)
+int mvn_loglik_sum_on(Ctx& c, const double* theta, const double* U, int ldu, int m, double* sum_out);
 // L = genD(0, chol=true, upper=false) (mcml_full.cpp:68): block-diagonal lower factor
 int mvn_gen_L(Ctx& c, const double* theta, bool chol);
 int potrf_lower(Ctx& c, double* A, int n, int lda);                          // in place

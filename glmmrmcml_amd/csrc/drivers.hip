@@ -18,6 +18,7 @@
 #include "optim.h"
 #include "trace.h"
 #include <cmath>
+#include <cstring>
 #include <random>
 
 namespace mcml {
@@ -65,6 +66,7 @@ struct McmlOptim {
     std::vector<double> beta, theta, cov_par_fix;
     double sigma;
     int trace, maxfun;
+    int theta_batch = 0;      // candidates per rank and round of the sharded theta-step (glmmr_mcml_ext.theta_batch)
     double model_var_par;     // M_->var_par_
 
     McmlOptim(Ctx& ctx, const double* start, int trace_, int maxfun_, double var_par0)
@@ -78,9 +80,68 @@ struct McmlOptim {
 
     BobyqaOpts bopts() const { BobyqaOpts o; o.iprint = trace; if (maxfun > 0) o.maxfun = maxfun; return o; }
 
+    // d_optim of a chain-sharded job (no reference counterpart: the reference is one process).  The
+    // factorisation of D(theta) does not shard -- replicated, it was 43 % of a rank's step at 8 GPUs -- but the
+    // optimiser's EVALUATIONS do: the sample columns are all-gathered once per iteration (every rank then holds all of
+    // u), the optimiser proposes `width` candidate thetas per round (optim.h bobyqa_batch), candidate j is evaluated on
+    // ALL columns by rank j mod world, and one all-reduce per round carries the values (each slot is nonzero on one
+    // rank).  Same objective (mcmloptim.h:56-68, likelihood.h:31-46, mcmldmatrix.h:23-41), sequential depth = rounds.
+    // The search runs over log(theta): the parameters are positive scales (lower bound 1e-6, mcmloptim.h:35-38) and
+    // the MVN log-likelihood is far closer to a quadratic there, which is what a round of simultaneous points needs.
+    // Every rank runs the same deterministic optimiser on the same values: no further agreement is needed.
+    int d_optim_sharded(int width)
+    {
+        MCML_TRY(gather_samples(c));
+        const int wr = comm_world(c), mall = c.mcols * wr;
+        batch_objective_fn fb = [&](const std::vector<std::vector<double>>& Zs, std::vector<double>* F) -> int {
+            const int nc = (int)Zs.size();
+            std::vector<double> vals(nc, 0.0), th(R);
+            const bool emu = c.world <= 1 && !c.comm && c.emu_world > 1;
+            int first_rc = MCML_OK;
+            for (int j = 0; j < nc; ++j) {
+                const bool mine = (j % wr) == c.rank;
+                if (!mine && !(emu && c.emu_mode == 1)) continue;
+                for (int i = 0; i < R; ++i) th[i] = std::exp(Zs[j][i]);
+                double sum = 0;
+                const int rc = mvn_loglik_sum_on(c, th.data(), c.Uall.d(), c.Uall.ld, mall, &sum);
+                if (rc == MCML_ENOTPD) vals[j] = HUGE_VAL;               // as eval_mvn: infinitely bad, not an error
+                else if (rc != MCML_OK) { vals[j] = NAN; if (first_rc == MCML_OK) first_rc = rc; }
+                else vals[j] = -1 * (sum / mall);
+                if (mine) ++c.theta_evals_own;
+            }
+            c.theta_rounds += 1; c.theta_evals_all += nc;
+            if (!emu) MCML_TRY(allreduce_host(c, vals.data(), nc));      // every slot is zero on all ranks but its owner
+            else if (c.emu_mode == 1) c.emu_trace.push_back(vals);
+            else {
+                MCML_REQUIRE(c.emu_pos < c.emu_trace.size() && (int)c.emu_trace[c.emu_pos].size() == nc,
+                             "rank emulation: replay ran past its record (round %zu)", c.emu_pos);
+                const std::vector<double>& rec = c.emu_trace[c.emu_pos++];
+                for (int j = 0; j < nc; ++j) {
+                    if ((j % wr) == c.rank) MCML_REQUIRE(vals[j] == rec[j] || (vals[j] != vals[j]), "rank emulation: replayed value differs from the recorded one (%.17g vs %.17g)", vals[j], rec[j]);
+                    else vals[j] = rec[j];
+                }
+            }
+            if (first_rc != MCML_OK) return first_rc;
+            for (double v : vals)         // a rank that failed put NaN in its slot: every rank stops here, together
+                if (v != v) { set_error("theta-step: a rank failed to evaluate its candidate"); return MCML_EHIP; }
+            *F = vals;
+            return MCML_OK; };
+        std::vector<double> z(R), lo(R, std::log(1e-6)), up(R, HUGE_VAL);
+        for (int i = 0; i < R; ++i) z[i] = std::log(std::max(theta[i], 1e-6));
+        BobyqaOpts o = bopts();
+        o.rhobeg = 0.25; o.rhoend = 1e-7;
+        BobyqaResult r;
+        MCML_TRY(bobyqa_batch(fb, z, lo, up, o, width, &r));
+        for (int i = 0; i < R; ++i) theta[i] = std::exp(r.x[i]);
+        return MCML_OK;
+    }
+
     // d_optim (mcmloptim.h:56-68), D_likelihood (likelihood.h:40-45)
     int d_optim()
     {
+        static const bool shard = !(getenv("GLMMR_MCML_THETA_SHARD") && !strcmp(getenv("GLMMR_MCML_THETA_SHARD"), "0"));
+        const int wr = comm_world(c);
+        if ((wr > 1 && shard) || theta_batch > 1) return d_optim_sharded(wr * std::max(1, theta_batch));
         objective_fn f = [&](const std::vector<double>& par, double* v) {
             double logl; MCML_TRY(eval_mvn(c, par.data(), &logl)); *v = -1 * logl; return (int)MCML_OK; };
         std::vector<double> lo(R, 1e-6), up(R, HUGE_VAL);
@@ -178,6 +239,7 @@ int drv_optim(Ctx& c, const double* start, int nstart, int trace, int mcnr, cons
     MCML_REQUIRE(start && nstart >= P + R + (is_gaussian(c.flink) ? 1 : 0), "start has %d values, need %d", nstart, P + R + (is_gaussian(c.flink) ? 1 : 0));
     MCML_REQUIRE(c.mcols > 0, "no samples u set");
     McmlOptim mc(c, start, trace, e ? e->maxfun : 0, 1.0);      // model built with var_par = 1 (mcml_optim.cpp:51)
+    mc.theta_batch = e ? e->theta_batch : 0;
     {
         PhaseRange r("mcml:beta-step");
         if (!mcnr) MCML_TRY(mc.l_optim()); else MCML_TRY(mc.mcnr());
@@ -247,6 +309,7 @@ int drv_full(Ctx& c, const double* start, int nstart, int mcnr, int m, int maxit
     MCML_TRY(model_update_beta(c, beta.data()));
     MCML_TRY(model_update_L(c));
     McmlOptim mc(c, start, trace, e ? e->maxfun : 0, var_par);                // :71
+    mc.theta_batch = e ? e->theta_batch : 0;
     double maxdiff = 1;
     int iter = 1;
     bool converged = false;

@@ -767,7 +767,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
     }
     c.mcols = ncols;
     c.niter = (C == 1) ? d : ncols;                                // mcmlmodel.h:73 vs mhmcmc.h:126 (D5)
-    c.zu_valid = false;
+    c.zu_valid = false; c.uall_valid = false;
     if (flags_out) MCML_HIP(hipMemcpyAsync(flags_out, d_flags.p, (size_t)C * total, hipMemcpyDeviceToHost, c.stream));
     if (probs_out) MCML_HIP(hipMemcpyAsync(probs_out, d_probs.p, sizeof(double) * (size_t)C * total, hipMemcpyDeviceToHost, c.stream));
     double dg[6] = {0, 0, 0, 0, 0, 0};

@@ -999,10 +999,16 @@ int potrf_lower_checked(Ctx& c, double* A, int n, int lda)
 int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out)
 {
     MCML_REQUIRE(c.mcols > 0 && c.U.d(), "mvn_ll: no samples set");
+    return mvn_loglik_sum_on(c, theta, c.U.d(), c.U.ld, c.mcols, sum_out);
+}
+
+int mvn_loglik_sum_on(Ctx& c, const double* theta, const double* Us, int ldu, int m, double* sum_out)
+{
+    MCML_REQUIRE(m > 0 && Us, "mvn_ll: no samples set");
     ThetaArg th;
     MCML_TRY(theta_arg(c, theta, th));
     const CovSpec& cs = c.cov;
-    const int Q = cs.N, m = c.mcols;
+    const int Q = cs.N;
     double* scal = c.scalars.d();
     const int32_t* dcov = c.d_cov.as<int32_t>();
     const CovBlock* dblk = c.d_blocks.as<CovBlock>();
@@ -1019,7 +1025,7 @@ int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out)
         dim3 grid((Q + 255) / 256, 1);
         int gy = 65536 / (int)grid.x; if (gy > m) gy = m; if (gy > 64) gy = 64; if (gy < 1) gy = 1;
         grid.y = gy;
-        hipLaunchKernelGGL(k_diag_ll, grid, dim3(256), 0, c.stream, c.U.d(), c.U.ld, Q, m, drb, dd, dc, part);
+        hipLaunchKernelGGL(k_diag_ll, grid, dim3(256), 0, c.stream, Us, ldu, Q, m, drb, dd, dc, part);
         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, part, (int)(grid.x * grid.y), 1.0, scal, 1);
         MCML_HIP(hipGetLastError());
     }
@@ -1034,7 +1040,7 @@ int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out)
         MCML_TRY(wb.ensure(idbytes + sizeof(double) * ids.size() * ny + 1024));
         MCML_HIP(hipMemcpyAsync(wb.p, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, c.stream));
         double* part = reinterpret_cast<double*>(static_cast<char*>(wb.p) + idbytes);
-        hipLaunchKernelGGL(k_small_ll, dim3((unsigned)ids.size(), ny), dim3(64), 0, c.stream, c.U.d(), c.U.ld, m,
+        hipLaunchKernelGGL(k_small_ll, dim3((unsigned)ids.size(), ny), dim3(64), 0, c.stream, Us, ldu, m,
                            wb.as<int>(), dblk, dcov, cs.rows, c.d_data.d(), th, part, c.scalars.as<int>() + 32);
         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, part, (int)ids.size() * ny, 1.0, scal, 1);
         MCML_HIP(hipGetLastError());
@@ -1065,7 +1071,7 @@ int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out)
             const double* Z; int ldz, zr, zc;        // the solved samples: zr x zc, sum of squares wanted
             if (aug) {
                 hipLaunchKernelGGL(k_transpose_in, dim3((d + 31) / 32, (m + 31) / 32), dim3(256), 0, c.stream,
-                                   c.U.d() + blk.matstart, c.U.ld, d, m, c.Dwork.d() + dp, c.Dwork.ld);
+                                   Us + blk.matstart, ldu, d, m, c.Dwork.d() + dp, c.Dwork.ld);
                 if (dp > d)        // the border column of the sample rows must be finite: it meets zeros only
                     MCML_HIP(hipMemsetAsync(c.Dwork.d() + dp + (size_t)d * c.Dwork.ld, 0, sizeof(double) * m, c.stream));
                 MCML_HIP(hipGetLastError());
@@ -1078,7 +1084,7 @@ int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out)
                 MCML_TRY(potrf_lower(c, c.Dwork.d(), d, c.Dwork.ld));
                 int gy = m < 256 ? m : 256;
                 hipLaunchKernelGGL(k_copy_block, dim3((d + 255) / 256, gy), dim3(256), 0, c.stream, c.Uwork.d(),
-                                   c.Uwork.ld, c.U.d() + blk.matstart, c.U.ld, d, m);
+                                   c.Uwork.ld, Us + blk.matstart, ldu, d, m);
                 MCML_HIP(hipGetLastError());
                 MCML_TRY(trsm_left_lower(c, c.Dwork.d(), c.Dwork.ld, d, c.Uwork.d(), c.Uwork.ld, m));
                 Z = c.Uwork.d(); ldz = c.Uwork.ld; zr = d; zc = m;

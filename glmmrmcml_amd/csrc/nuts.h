@@ -847,7 +847,7 @@ int nuts_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_nut
         EpiAxpby epi{c.U.d(), c.U.ld, 1.0, 0.0};
         MCML_TRY(launch_gemm<false>(c.stream, Q, ncols, Q, c.L.d(), c.L.ld, samp.d(), samp.ld, epi));
     }
-    c.mcols = ncols; c.niter = ncols; c.zu_valid = false;
+    c.mcols = ncols; c.niter = ncols; c.zu_valid = false; c.uall_valid = false;
     if (depth_out) MCML_HIP(hipMemcpyAsync(depth_out, d_depth.p, sizeof(int) * (size_t)C * total, hipMemcpyDeviceToHost, c.stream));
     if (nleap_out) MCML_HIP(hipMemcpyAsync(nleap_out, d_nleap.p, sizeof(int) * (size_t)C * total, hipMemcpyDeviceToHost, c.stream));
     if (eps_out) MCML_HIP(hipMemcpyAsync(eps_out, d_eps.p, sizeof(double) * (size_t)C * total, hipMemcpyDeviceToHost, c.stream));

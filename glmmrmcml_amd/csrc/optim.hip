@@ -108,6 +108,8 @@ class Bobyqa {
 public:
     Bobyqa(const objective_fn& f, const vec& x0, const vec& lo, const vec& up, const BobyqaOpts& o)
         : f_(f), n_((int)x0.size()), lo_(lo), up_(up), o_(o), x0_(x0) {}
+    Bobyqa(const batch_objective_fn& fb, const vec& x0, const vec& lo, const vec& up, const BobyqaOpts& o)
+        : f_(none_), fb_(&fb), n_((int)x0.size()), lo_(lo), up_(up), o_(o), x0_(x0) {}
 
     int run(BobyqaResult* res)
     {
@@ -271,8 +273,266 @@ public:
         return MCML_OK;
     }
 
+    // ---------------------------------------------------------------- the batch schedule (optim.h)
+    int run_batch(int width, BobyqaResult* res)
+    {
+        const int n = n_;
+        const int W = std::max(1, width);
+        const int nfull = (n + 1) * (n + 2) / 2;
+        if (o_.npt > 0) npt_ = std::min(std::max(o_.npt, n + 2), nfull);
+        else npt_ = (nfull <= std::max(W, 2 * n + 1)) ? nfull : 2 * n + 1;
+        // radius and start exactly as run() chooses them
+        double xmax = 0; for (double v : x0_) xmax = std::max(xmax, std::fabs(v));
+        double rhobeg = o_.rhobeg > 0 ? o_.rhobeg : std::min(0.95, 0.2 * xmax);
+        if (!(rhobeg > 0)) rhobeg = 0.1;
+        for (int i = 0; i < n; ++i) {
+            double rng = up_[i] - lo_[i];
+            if (std::isfinite(rng)) { if (!(rng > 0)) { set_error("bobyqa: empty bound interval"); return MCML_EINVAL; } rhobeg = std::min(rhobeg, 0.5 * rng * 0.999); }
+        }
+        if (!(o_.rhobeg > 0)) {
+            const double near = 1e-3 * rhobeg;
+            for (int i = 0; i < n; ++i) {
+                double xi = std::min(std::max(x0_[i], lo_[i]), up_[i]);
+                const double dl = xi - lo_[i], du = up_[i] - xi;
+                if (std::isfinite(dl) && dl > 0) { if (dl < near) x0_[i] = lo_[i]; else rhobeg = std::min(rhobeg, 0.5 * dl); }
+                if (std::isfinite(du) && du > 0) { if (du < near) x0_[i] = up_[i]; else rhobeg = std::min(rhobeg, 0.5 * du); }
+            }
+        }
+        const double rhoend = o_.rhoend > 0 ? std::min(o_.rhoend, rhobeg) : 1e-6 * rhobeg;
+        vec x = x0_;
+        for (int i = 0; i < n; ++i) {
+            x[i] = std::min(std::max(x[i], lo_[i]), up_[i]);
+            if (x[i] - lo_[i] < rhobeg && x[i] != lo_[i]) x[i] = (x[i] - lo_[i] < 0.5 * rhobeg) ? lo_[i] : lo_[i] + rhobeg;
+            if (up_[i] - x[i] < rhobeg && x[i] != up_[i]) x[i] = (up_[i] - x[i] < 0.5 * rhobeg) ? up_[i] : up_[i] - rhobeg;
+        }
+        nf_ = 0; rc_ = 0;
+        int rounds = 0;
+        auto clampv = [&](vec& y) { for (int i = 0; i < n; ++i) y[i] = std::min(std::max(y[i], lo_[i]), up_[i]); };
+        auto dist = [&](const vec& p, const vec& q) { double t = 0; for (int i = 0; i < n; ++i) { double e = p[i] - q[i]; t += e * e; } return std::sqrt(t); };
+
+        // ---- initial design: x, x +- rhobeg e_i (run()'s points), the pair points of a full quadratic; a last round
+        // that is not full also takes the opposite diagonals (they compete for the best point only)
+        std::vector<vec> P0(1, x);
+        vec s1(n, 0.0);
+        for (int i = 0; i < n; ++i) {
+            double step = rhobeg;
+            if (up_[i] - x[i] < rhobeg * 0.999) step = -rhobeg;
+            vec y = x; y[i] = std::min(std::max(x[i] + step, lo_[i]), up_[i]); s1[i] = y[i] - x[i];
+            P0.push_back(y);
+        }
+        for (int i = 0; i < n; ++i) {
+            double step = -rhobeg;
+            if (x[i] - lo_[i] < rhobeg * 0.999) step = 2 * rhobeg;
+            if (up_[i] - x[i] < rhobeg * 0.999) step = -2 * rhobeg;
+            vec y = x; y[i] = std::min(std::max(x[i] + step, lo_[i]), up_[i]);
+            P0.push_back(y);
+        }
+        for (int i = 0; i < n && (int)P0.size() < npt_; ++i)
+            for (int j = i + 1; j < n && (int)P0.size() < npt_; ++j) { vec y = x; y[i] += s1[i]; y[j] += s1[j]; P0.push_back(y); }
+        P0.resize(npt_);
+        const int budget0 = std::min(o_.maxfun, ((npt_ + W - 1) / W) * W);
+        for (int i = 0; i < n && (int)P0.size() < budget0; ++i)
+            for (int j = i + 1; j < n && (int)P0.size() < budget0; ++j) {
+                vec y = x; y[i] += s1[i]; y[j] -= s1[j];
+                if (y[j] < lo_[j] || y[j] > up_[j]) continue;
+                P0.push_back(y);
+            }
+        if ((int)P0.size() > o_.maxfun) P0.resize(std::max(1, o_.maxfun));
+        vec F0;
+        for (size_t at = 0; at < P0.size(); at += W) {
+            std::vector<vec> X(P0.begin() + at, P0.begin() + std::min(P0.size(), at + (size_t)W));
+            vec F;
+            if (!eval_batch(X, &F)) return rc_;
+            ++rounds;
+            F0.insert(F0.end(), F.begin(), F.end());
+        }
+        if ((int)P0.size() < npt_) {            // the budget ended inside the initial design
+            size_t kb = std::min_element(F0.begin(), F0.end()) - F0.begin();
+            res->x = P0[kb]; res->fval = F0[kb]; res->nfev = nf_; res->status = 1; res->rounds = rounds;
+            return MCML_OK;
+        }
+        Y_.assign(P0.begin(), P0.begin() + npt_); F_.assign(F0.begin(), F0.begin() + npt_);
+        kopt_ = (int)(std::min_element(F_.begin(), F_.end()) - F_.begin());
+        q_.init(n); q_.c = 0; xb_ = Y_[kopt_];
+        if (!refit(true)) { set_error("bobyqa: initial interpolation set is degenerate"); return MCML_EINVAL; }
+        double rho = rhobeg, delta = rho;
+        for (size_t k = npt_; k < P0.size(); ++k)
+            if (F0[k] < F_[kopt_]) {
+                move_base_to_opt();
+                int knew = pick_replace(P0[k], true, delta);
+                if (knew >= 0) replace(knew, P0[k], F0[k]);
+                if (rc_) return rc_;
+            }
+
+        struct Cand { vec x; int kind; int knew; double radius, vquad, dnorm; };
+        int status = 0;
+        for (;;) {
+            if (nf_ >= o_.maxfun) { status = 1; break; }
+            move_base_to_opt();
+            const int room = std::min(W, o_.maxfun - nf_);
+            vec a(n), b(n);
+            for (int i = 0; i < n; ++i) { a[i] = lo_[i] - xb_[i]; b[i] = up_[i] - xb_[i]; }
+            vec d1 = trust_step(q_, delta, a, b, nullptr);
+            const double dn1 = std::min(delta, norm2(d1));
+            const bool short_step = dn1 < 0.5 * rho;
+            // the rho that follows this one (Powell's schedule; after a short step never larger than twice that step)
+            double rho_next = rho;
+            {
+                const double r = rho / rhoend;
+                rho_next = (r <= 16.0) ? rhoend : (r <= 250.0) ? std::sqrt(r) * rhoend : 0.1 * rho;
+                if (short_step) rho_next = std::max(rhoend, std::min(rho_next, std::max(2.0 * dn1, 1e-3 * rho)));
+            }
+            const bool last_level = !(rho > rhoend);
+            if (o_.iprint > 1) fprintf(stderr, "bobyqa_batch: round %d nf=%d f=%.12g rho=%.3g delta=%.3g dnorm=%.3g%s\n", rounds, nf_, F_[kopt_], rho, delta, dn1, short_step ? " (short)" : "");
+            std::vector<Cand> cs;
+            auto push_tr = [&](const vec& d, double radius, bool dedup) {
+                vec xn(n); for (int i = 0; i < n; ++i) xn[i] = std::min(std::max(xb_[i] + d[i], lo_[i]), up_[i]);
+                vec dd(n); for (int i = 0; i < n; ++i) dd[i] = xn[i] - xb_[i];
+                const double dn = norm2(dd);
+                if (!(dn > 1e-3 * rhoend)) return;
+                if (dedup) for (const Cand& c : cs) if (dist(c.x, xn) < 0.1 * rho) return;
+                cs.push_back(Cand{xn, 0, -1, radius, q_.eval(dd) - q_.c, dn});
+            };
+            // the trust-region points are chosen AFTER the geometry points below (which reserve their slots first)
+            double rmin = delta;
+            auto add_tr_points = [&](int slots) {
+                if (short_step) { push_tr(d1, delta, false); return; }
+                const bool boundary = dn1 >= 0.999 * delta;
+                // a search over the radius in one round: along the trust-region path when the step ends on the
+                // boundary (delta, 2 delta, delta/2, ...), along the step itself when the model's minimiser is interior
+                const double mult[6] = {1.0, 2.0, 0.5, 4.0, 0.25, 8.0};
+                int added = 0;
+                for (int t = 0; t < 6 && added < slots; ++t) {
+                    const double r = mult[t] * (boundary ? delta : dn1);
+                    if (r < 0.5 * rho) continue;
+                    if (!boundary && mult[t] > 2.0) continue;
+                    const size_t before = cs.size();
+                    if (t == 0) push_tr(d1, r, true);
+                    else if (boundary) push_tr(trust_step(q_, r, a, b, nullptr), r, true);
+                    else { vec d(n); for (int i = 0; i < n; ++i) d[i] = mult[t] * d1[i]; push_tr(d, r, true); }
+                    if (cs.size() > before) { rmin = std::min(rmin, r); ++added; }
+                }
+            };
+            // replacements for the badly placed interpolation points, each chosen against the set as it will be.  After
+            // a short step rho is about to shrink: place them for the next rho.
+            int ngeom = 0;
+            if (!(short_step && last_level)) {
+                const double rho_g = short_step ? rho_next : rho;
+                const double delta_g = short_step ? std::max(0.5 * rho, rho_next) : delta;
+                const double far2 = std::max(4.0 * delta_g * delta_g, 100.0 * rho_g * rho_g);
+                const std::vector<vec> Ysave = Y_;
+                std::vector<char> tried(npt_, 0);
+                const int reserve = short_step ? 1 : (room >= 6 ? 3 : room >= 3 ? 2 : 1);
+                while ((int)cs.size() < room - reserve) {
+                    int knew = -1; double dmax = far2;
+                    for (int k = 0; k < npt_; ++k) {
+                        if (k == kopt_ || tried[k]) continue;
+                        const double sdist = dist(Y_[k], xb_); if (sdist * sdist > dmax) { dmax = sdist * sdist; knew = k; }
+                    }
+                    if (knew < 0) break;
+                    tried[knew] = 1;
+                    const double dk = std::sqrt(dmax);
+                    const double adelt = std::max(std::min(0.1 * dk, delta_g), rho_g);
+                    vec xn;
+                    if (!geometry_point(knew, adelt, &xn)) continue;
+                    bool dup = false;
+                    for (const Cand& c : cs) if (dist(c.x, xn) < 0.1 * rho_g) dup = true;
+                    for (int k = 0; k < npt_; ++k) if (k != knew && dist(Y_[k], xn) < 0.1 * rho_g) dup = true;
+                    if (dup) continue;
+                    Y_[knew] = xn;
+                    if (!build_W()) { Y_[knew] = Ysave[knew]; build_W(); continue; }
+                    cs.push_back(Cand{xn, 1, knew, adelt, 0.0, dist(xn, xb_)});
+                    ++ngeom;
+                }
+                Y_ = Ysave; build_W();
+            }
+            add_tr_points(std::min(room - (int)cs.size(), short_step ? 1 : (room >= 6 ? 3 : room >= 3 ? 2 : 1)));
+            // slots still free: a stencil around the point the model steps to -- the values the NEXT model wants if
+            // the step is taken, and a direct check of it (the stencil brackets the minimiser) if it is not
+            if ((int)cs.size() < room && !cs.empty() && cs.back().kind == 0 && !(short_step && last_level)) {
+                const double rho_g = short_step ? rho_next : rho;
+                const double hst = short_step ? rho_next : std::max(rho, 0.5 * dn1);
+                vec xc(n); for (int i = 0; i < n; ++i) xc[i] = std::min(std::max(xb_[i] + d1[i], lo_[i]), up_[i]);
+                auto push_st = [&](const vec& y0) {
+                    vec y = y0; clampv(y);
+                    for (const Cand& c : cs) if (dist(c.x, y) < 0.25 * hst) return;
+                    for (int k = 0; k < npt_; ++k) if (dist(Y_[k], y) < std::max(0.1 * rho_g, 0.25 * hst)) return;
+                    cs.push_back(Cand{y, 2, -1, hst, 0.0, dist(y, xb_)});
+                };
+                for (int sgn = 1; sgn >= -1 && (int)cs.size() < room; sgn -= 2)
+                    for (int i = 0; i < n && (int)cs.size() < room; ++i) { vec y = xc; y[i] += sgn * hst; push_st(y); }
+                const double hd = hst / std::sqrt(2.0);
+                for (int si = 1; si >= -1 && (int)cs.size() < room; si -= 2)
+                    for (int sj = 1; sj >= -1 && (int)cs.size() < room; sj -= 2)
+                        for (int i = 0; i < n && (int)cs.size() < room; ++i)
+                            for (int j = i + 1; j < n && (int)cs.size() < room; ++j) { vec y = xc; y[i] += si * hd; y[j] += sj * hd; push_st(y); }
+            }
+            bool improved_tr = false;
+            if (!cs.empty()) {
+                std::vector<vec> X; for (const Cand& c : cs) X.push_back(c.x);
+                vec F;
+                if (!eval_batch(X, &F)) return rc_;
+                ++rounds;
+                const double fopt0 = F_[kopt_];
+                for (size_t i = 0; i < cs.size(); ++i)
+                    if (cs[i].kind == 1) { replace(cs[i].knew, cs[i].x, F[i]); if (rc_) return rc_; }
+                // trust-region points: worst first, so that the best one enters last and becomes the base point
+                std::vector<int> tr;
+                for (size_t i = 0; i < cs.size(); ++i) if (cs[i].kind != 1) tr.push_back((int)i);
+                std::sort(tr.begin(), tr.end(), [&](int p, int q2) { return F[p] > F[q2] || (F[p] == F[q2] && p > q2); });
+                int ibest = -1;
+                for (int i : tr) {
+                    if (cs[i].kind == 0 && (ibest < 0 || F[i] <= F[ibest])) ibest = i;
+                    move_base_to_opt();
+                    int knear = -1;
+                    for (int k = 0; k < npt_; ++k) if (dist(Y_[k], cs[i].x) < 0.1 * rho) { knear = k; break; }
+                    if (knear >= 0) {           // (nearly) on top of a point of the set: takes its place if it is better
+                        if (F[i] < F_[knear]) {
+                            const vec oldx = Y_[knear]; const double oldf = F_[knear];
+                            Y_[knear] = cs[i].x; F_[knear] = F[i];
+                            if (!refit(true)) { Y_[knear] = oldx; F_[knear] = oldf; build_W(); }
+                            kopt_ = (int)(std::min_element(F_.begin(), F_.end()) - F_.begin());
+                        }
+                        continue;
+                    }
+                    const int knew = pick_replace(cs[i].x, F[i] < F_[kopt_], std::max(delta, rho));
+                    if (knew >= 0) { replace(knew, cs[i].x, F[i]); if (rc_) return rc_; }
+                }
+                if (ibest >= 0 && !short_step) {
+                    const Cand& cb = cs[ibest];
+                    if (F[ibest] < fopt0) {
+                        improved_tr = true;
+                        const double ratio = cb.vquad < 0.0 ? (F[ibest] - fopt0) / cb.vquad : -1.0;
+                        const double h = 0.5 * cb.radius;
+                        if (ratio <= 0.1) delta = std::min(h, cb.dnorm);
+                        else if (ratio <= 0.7) delta = std::max(h, cb.dnorm);
+                        else delta = std::max(h, 2.0 * cb.dnorm);
+                    } else delta = 0.5 * rmin;
+                    if (delta <= 1.5 * rho) delta = rho;
+                }
+                if (F_[kopt_] < fopt0) improved_tr = true;      // a stencil or geometry point may be the one that improved
+                if (o_.iprint > 1) fprintf(stderr, "bobyqa_batch:   %zu points (%d geometry) -> f=%.12g delta=%.3g\n", cs.size(), ngeom, F_[kopt_], delta);
+            }
+            bool reduce = false;
+            if (short_step) reduce = true;
+            else if (cs.empty()) { if (delta > rho) delta = rho; else reduce = true; }
+            else if (!improved_tr && ngeom == 0 && rmin <= rho) reduce = true;
+            if (reduce) {
+                if (last_level) break;
+                delta = std::max(0.5 * rho, rho_next);
+                rho = rho_next;
+                if (o_.iprint > 0) fprintf(stderr, "bobyqa_batch: rho -> %.3g  nf=%d rounds=%d f=%.12g\n", rho, nf_, rounds, F_[kopt_]);
+            }
+        }
+        kopt_ = (int)(std::min_element(F_.begin(), F_.end()) - F_.begin());
+        res->x = Y_[kopt_]; res->fval = F_[kopt_]; res->nfev = nf_; res->status = status; res->rounds = rounds;
+        return MCML_OK;
+    }
+
 private:
+    objective_fn none_;
     const objective_fn& f_;
+    const batch_objective_fn* fb_ = nullptr;
     int n_, npt_ = 0, nf_ = 0, rc_ = 0, kopt_ = 0;
     vec lo_, up_;
     BobyqaOpts o_;
@@ -285,11 +545,29 @@ private:
     double eval(const vec& x)
     {
         double v = 0;
-        int rc = f_(x, &v);
+        int rc;
+        if (fb_) {                      // batch mode: a batch of one (the rare rescue path)
+            std::vector<vec> X(1, x); vec F;
+            rc = (*fb_)(X, &F);
+            if (!rc) v = F.empty() ? HUGE_VAL : F[0];
+        } else rc = f_(x, &v);
         ++nf_;
         if (rc) { rc_ = rc; return 0; }
         if (v != v) v = HUGE_VAL;       // NaN objective: treat as +inf
         return v;
+    }
+
+    // one exchange: every point of X evaluated (by whoever owns it), all values returned
+    bool eval_batch(const std::vector<vec>& X, vec* F)
+    {
+        F->assign(X.size(), 0.0);
+        if (X.empty()) return true;
+        int rc = (*fb_)(X, F);
+        nf_ += (int)X.size();
+        if (rc) { rc_ = rc; return false; }
+        if (F->size() != X.size()) { rc_ = MCML_EINVAL; set_error("bobyqa_batch: objective returned %zu values for %zu points", F->size(), X.size()); return false; }
+        for (double& v : *F) if (v != v) v = HUGE_VAL;
+        return true;
     }
 
     void move_base_to_opt()
@@ -465,6 +743,39 @@ int bobyqa(const objective_fn& f, const std::vector<double>& x0, const std::vect
     if (const char* t = getenv("GLMMR_MCML_BOBYQA_TRACE")) o.iprint = atoi(t);
     Bobyqa b(f, x0, lower, upper, o);
     return b.run(res);
+}
+
+int bobyqa_batch(const batch_objective_fn& f, const std::vector<double>& x0, const std::vector<double>& lower,
+                 const std::vector<double>& upper, const BobyqaOpts& opts, int width, BobyqaResult* res)
+{
+    MCML_REQUIRE(res && !x0.empty() && lower.size() == x0.size() && upper.size() == x0.size() && width >= 1, "bobyqa_batch: bad arguments");
+    BobyqaOpts o = opts;
+    if (const char* t = getenv("GLMMR_MCML_BOBYQA_TRACE")) o.iprint = atoi(t);
+    if (x0.size() == 1) {
+        // as bobyqa(): one parameter is embedded in two dimensions
+        batch_objective_fn f2 = [&](const std::vector<std::vector<double>>& X, std::vector<double>* F) {
+            std::vector<std::vector<double>> X1; for (const auto& x : X) X1.push_back(std::vector<double>(1, x[0]));
+            int rc = f(X1, F);
+            if (!rc && F->size() == X.size()) for (size_t i = 0; i < X.size(); ++i) (*F)[i] += X[i][1] * X[i][1];
+            return rc; };
+        std::vector<double> x2{x0[0], 0.0}, l2{lower[0], -1.0}, u2{upper[0], 1.0};
+        if (!(o.rhobeg > 0)) { double a = std::fabs(x0[0]); o.rhobeg = std::min(0.95, 0.2 * a); if (!(o.rhobeg > 0)) o.rhobeg = 0.1; }
+        BobyqaResult r2;
+        Bobyqa b(f2, x2, l2, u2, o);
+        int rc = width == 1 ? b.run(&r2) : b.run_batch(width, &r2);
+        if (width == 1) r2.rounds = r2.nfev;
+        if (rc) return rc;
+        res->x.assign(1, r2.x[0]); res->nfev = r2.nfev; res->status = r2.status; res->rounds = r2.rounds;
+        res->fval = r2.fval - r2.x[1] * r2.x[1];
+        return MCML_OK;
+    }
+    Bobyqa b(f, x0, lower, upper, o);
+    if (width == 1) {       // nothing to run side by side: the sequential schedule, one point per exchange
+        int rc = b.run(res);
+        res->rounds = res->nfev;
+        return rc;
+    }
+    return b.run_batch(width, res);
 }
 
 // ---------------------------------------------------------------- finite differences

@@ -3,12 +3,15 @@
 One process per GPU.  Independent HMC chains / sample columns shard naturally:
 rank r owns global chains [r*C, (r+1)*C); ZL, X, y and L are replicated; the RNG
 streams are keyed by the GLOBAL chain id, so a chain's draws do not depend on
-how many ranks there are.  The only exchange is an all-reduce (sum, f64) of the
-per-chain sufficient statistics: P*P + P + 2 doubles for the MCNR beta-step and
-2 doubles (sum, count) per objective evaluation of the MCEM / theta steps.  The
-payload is tiny (latency-bound), so it is ONE collective per evaluation on the
-stream the kernels run on.  torch.distributed's "nccl" backend is RCCL on ROCm
-and runs over xGMI between the GPUs of a node.
+how many ranks there are.  Exchanges: an all-reduce (sum, f64) of the per-chain
+sufficient statistics -- P*P + P + 2 doubles for the MCNR beta-step, 2 doubles
+(sum, count) per objective evaluation of the MCEM step.  The theta-step shards
+over CANDIDATES instead (csrc/drivers.hip d_optim_sharded): one all-gather of the
+sample columns per iteration, then every rank evaluates one candidate theta per
+round on all columns and one all-reduce per round carries the values.  The small
+payloads are latency-bound: ONE collective per exchange, on the stream the kernels
+run on.  torch.distributed's "nccl" backend is RCCL on ROCm and runs over xGMI
+between the GPUs of a node.
 """
 import ctypes as C
 
@@ -71,29 +74,39 @@ def init_native_rccl(ctx, rank, world, group=None, device=None):
     import torch.distributed as dist
     from . import api
     dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
-    ok, uid = 1, bytes(128)
+
+    def agreed(ok, what, err):
+        """every rank reaches this all-reduce whatever happened locally; raises on all ranks or on none"""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) != 1:
+            raise RuntimeError(what + ("" if ok else ": %r" % (err,)))
+
+    # 1. everything a rank can check on its own: librccl resolves (rank 0's id is the one that is used), rank / world
+    ok, uid, err = True, bytes(128), None
     try:
-        uid = api.rccl_unique_id()          # also proves that librccl resolves on this rank
+        uid = api.rccl_unique_id()
+        if not (0 <= int(rank) < int(world)):
+            raise ValueError("rank %r of %r" % (rank, world))
     except Exception as e:                  # noqa: BLE001
-        ok = 0
-        err = e
-    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) != 1:
-        raise RuntimeError("librccl is not usable on every rank" + ("" if ok else ": %r" % (err,)))
+        ok, err = False, e
+    agreed(ok, "librccl is not usable on every rank", err)
     t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
     dist.broadcast(t, src=0, group=group)
-    ctx.comm_init_rccl(bytes(t.cpu().tolist()), rank, world)
-    # self-test of the new communicator on known values before anything depends on it; the verdict is shared
-    good = 1
+    # 2. ncclCommInitRank: itself a collective -- after step 1 only the collective can fail, and the outcome is shared
+    ok, err = True, None
+    try:
+        ctx.comm_init_rccl(bytes(t.cpu().tolist()), rank, world)
+    except Exception as e:                  # noqa: BLE001
+        ok, err = False, e
+    agreed(ok, "ncclCommInitRank failed on some rank", err)
+    # 3. self-test of the new communicator on known values before anything depends on it
+    ok, err = True, None
     try:
         got = ctx.comm_allreduce([rank + 1.0, 1.0, 0.5 * (rank + 1.0)])
         tri = world * (world + 1) / 2.0
         if not (got[0] == tri and got[1] == float(world) and got[2] == 0.5 * tri):
-            good, err = 0, RuntimeError("native all-reduce returned %r on rank %d of %d" % (got.tolist(), rank, world))
+            ok, err = False, RuntimeError("native all-reduce returned %r on rank %d of %d" % (got.tolist(), rank, world))
     except Exception as e:                  # noqa: BLE001
-        good, err = 0, e
-    flag = torch.tensor([good], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) != 1:
-        raise RuntimeError("native RCCL all-reduce failed its self-test" + ("" if good else ": %r" % (err,)))
+        ok, err = False, e
+    agreed(ok, "native RCCL all-reduce failed its self-test", err)

@@ -88,11 +88,19 @@ int glmmr_mcml_ctx_comm_allreduce(glmmr_mcml_ctx* ctx, double* vals, int n);
 
 /* collectives issued so far, doubles summed, 1 if the native communicator is in use (all nullable) */
 int glmmr_mcml_ctx_comm_stats(glmmr_mcml_ctx* ctx, long long* calls, long long* doubles, int* native);
+/* out6 = [all-gathers issued, doubles received by them, theta-step rounds (one all-reduce each), candidate thetas
+ * evaluated on this rank, candidate thetas evaluated over all ranks, 0] since the context was made */
+int glmmr_mcml_ctx_shard_stats(glmmr_mcml_ctx* ctx, long long* out6);
 
 /* samples u (Q x ncols, this rank's columns).  niter = columns the beta-step
  * reads (mcmlmodel.h:73,296); the theta-step reads all ncols (mcmldmatrix.h:24). */
 int glmmr_mcml_set_u(glmmr_mcml_ctx* ctx, const double* u, int Q, int ncols, int niter);
 int glmmr_mcml_get_u(glmmr_mcml_ctx* ctx, double* u, int ldu);
+/* All ranks' samples (Q x world * ncols, rank r's columns at column r * ncols): what the reference's mcml_full
+ * returns as u (mcml_full.cpp:144-145) when the chains are sharded.  COLLECTIVE unless the samples have not changed
+ * since the last theta-step (which gathers them): after glmmr_mcml_ctx_full it moves no data between ranks.
+ * ncols_out (nullable) = columns written.  Single process: the same as glmmr_mcml_get_u. */
+int glmmr_mcml_get_u_all(glmmr_mcml_ctx* ctx, double* u, int ldu, int* ncols_out);
 
 /* MCMLDmatrix::loglik(u) at theta (mcmldmatrix.h:23-41) */
 int glmmr_mcml_ctx_mvn_ll(glmmr_mcml_ctx* ctx, const double* theta, double* out);
@@ -181,6 +189,9 @@ typedef struct glmmr_mcml_ext {
     int      chains;    /* <= 1: the reference's single sequential chain; C: C concurrent chains */
     int      maxfun;    /* objective evaluations per optimiser call; 0 = 10000 (minqa default) */
     int      device;    /* HIP device ordinal */
+    int      theta_batch; /* candidate thetas per rank and round of the theta-step.  0: a sharded job (world > 1) runs
+                             the batch schedule with one candidate per rank and round, a single process the reference's
+                             sequential BOBYQA; k >= 2 forces the batch schedule with world * k candidates per round */
 } glmmr_mcml_ext;
 
 /* gen_u_samples(y, X, Z, L, beta, family, sigma, warmup_iter, m) -> Q x m      -- R/gen_u_samples.R:38-69
@@ -295,6 +306,14 @@ int glmmr_mcml_mvn_ll(const int32_t* cov, int cov_rows, const double* data, int 
                       const double* u, int Q, int m, double* out);
 
 /* ---- test hooks (building blocks exposed for tests/ and bench.py only) ---- */
+/* One rank of an N-rank job on ONE GPU, for timing what a rank executes when no N-GPU node is at hand (bench.py
+ * --as-rank-of N).  The context stays a single process; its peers are emulated as copies of itself: a sum is N times
+ * the local value, the sample all-gather N copies of the local block.  mode 1: the candidate thetas of ALL ranks are
+ * evaluated here and their values recorded; mode 2: only rank 0's share is evaluated, the other values come from the
+ * record (the same fit must be re-run from the same start: every own value is checked against the record) -- the
+ * launches of mode 2 are exactly those of rank 0 of the real job; what it leaves out is the time of the collectives
+ * themselves.  world <= 1 switches the emulation off. */
+int glmmr_mcml_dbg_emulate_world(glmmr_mcml_ctx* ctx, int world, int mode);
 /* shader-clock timestamps of the phases of one 128 x 128 Cholesky leaf: [start, loaded, sum (a) diagonal tiles,
  * sum (b) panel solves, sum (c) trailing updates, factor done, L written, inverse diag done, inverse done, end] */
 int glmmr_mcml_dbg_leaf_profile(glmmr_mcml_ctx* ctx, unsigned long long* out10);
@@ -319,6 +338,11 @@ typedef double (*glmmr_mcml_objective)(const double* x, int n, void* user);
 int glmmr_mcml_dbg_bobyqa(glmmr_mcml_objective f, void* user, int n, const double* x0, const double* lower,
                           const double* upper, double rhobeg, double rhoend, int maxfun, double* x_out,
                           double* f_out, int* nfev_out);
+/* the batch schedule of the same optimiser (csrc/optim.h bobyqa_batch): `width` points per round; rounds_out = the
+ * sequential depth.  The callback is still called once per point. */
+int glmmr_mcml_dbg_bobyqa_batch(glmmr_mcml_objective f, void* user, int n, const double* x0, const double* lower,
+                                const double* upper, double rhobeg, double rhoend, int maxfun, int width,
+                                double* x_out, double* f_out, int* nfev_out, int* rounds_out);
 int glmmr_mcml_dbg_fd_hessian(glmmr_mcml_objective f, void* user, int n, const double* x, double ndeps,
                               int usebounds, const double* lower, const double* upper, double* H);
 int glmmr_mcml_dbg_dgemm_bench(int M, int N, int K, int b_nmajor, int iters, int force_tile,

@@ -1,11 +1,15 @@
 """The N > 1 path of the PRODUCT (csrc/comm.hip, model.hip::model_mcnr_stats, drivers.hip: chain_offset =
-rank * chains, every statistic all-reduced) on one GPU:
+rank * chains, every statistic all-reduced, the theta-step sharded over candidate thetas) on one GPU:
 
   * two contexts, rank 0 and rank 1 of world 2, driven from two host threads; the reduce hook sums the two
     contexts' device buffers (fixed order, barrier either side) -- what RCCL does between two GPUs.  mcml_full
     over 2 x C chains must reproduce the single-context run with 2C chains (src/mcml_full.cpp:83-145): beta,
-    theta, sigma, and each rank's u = its columns of the unsharded u; the number of collectives and their payloads
-    are the ones DESIGN.md section 7 states (P*P+P+2 doubles per MCNR step, 2 per objective evaluation);
+    theta, sigma, each rank's u = its columns of the unsharded u and get_u_all = all of it (mcml_full.cpp:144-145);
+    the number of collectives and their payloads are the ones DESIGN.md section 7 states (P*P+P+2 doubles per MCNR
+    step, 2 per MCEM objective evaluation, per iteration one all-gather of the samples and one all-reduce of
+    `world` candidate values per round of the theta-step);
+  * one rank of an emulated 8-rank job (bench.py --as-rank-of 8): record and replay give the same fit, the replay
+    evaluates an eighth of the candidates;
   * the native RCCL communicator (ncclAllReduce on the context's stream, no callback) on a 1-rank group: same
     numbers as no communicator, collectives counted.
 """
@@ -68,6 +72,9 @@ def _run_world2(d, kw, Cn):
                 r = ctx.mcml_full(d["start"], chains=Cn, m=Cn, **kw)
                 r["u"] = ctx.get_u()
                 r["comm"] = ctx.comm_stats()
+                r["shard"] = ctx.shard_stats()
+                r["u_all"] = ctx.get_u_all()          # the theta-step gathered them: no further collective
+                assert ctx.comm_stats() == r["comm"] and ctx.shard_stats() == r["shard"]
                 out[rank] = r
         except Exception as e:
             err[rank] = e
@@ -107,16 +114,59 @@ def test_world2_contexts_equal_one_context_with_all_chains(gen, gkw, mcnr):
         # rank r holds global chains [r*C, (r+1)*C): one draw per chain -> its columns of the unsharded u
         assert out[r]["u"].shape == (d["Q"], Cn)
         assert np.abs(out[r]["u"] - whole["u"][:, r * Cn:(r + 1) * Cn]).max() < 2e-5
-        assert not out[r]["comm"]["native"] and out[r]["comm"]["calls"] == len(calls[r])
+        assert not out[r]["comm"]["native"]
+        assert out[r]["comm"]["calls"] + out[r]["shard"]["gathers"] == len(calls[r])
+        assert np.array_equal(out[r]["u_all"][:, r * Cn:(r + 1) * Cn], out[r]["u"])
+        assert np.abs(out[r]["u_all"] - whole["u"]).max() < 2e-5
     assert np.array_equal(out[0]["beta"], out[1]["beta"]) and np.array_equal(out[0]["theta"], out[1]["theta"])
+    assert np.array_equal(out[0]["u_all"], out[1]["u_all"])
     assert calls[0] == calls[1] and len(calls[0]) > 0
+    Q = d["Q"]
+    ld = -(-Q // 32) * 32                               # leading dimension of the resident sample matrix
+    gather = 2 * ld * Cn                                # the all-gather through a summing hook: both blocks
+    sh = out[0]["shard"]
+    # per iteration: ONE all-gather of the samples (+ the 2-double agreement on the block width in front of it), then
+    # one all-reduce of <= world candidate values per round of the theta-step; each rank evaluates half the candidates
+    assert calls[0].count(gather) == 2 and sh["gathers"] == 2 and sh["gather_doubles"] == 2 * gather
+    assert sh["theta_rounds"] >= 2 * 3 and sh["theta_evals_own"] + out[1]["shard"]["theta_evals_own"] == sh["theta_evals_all"]
+    assert abs(sh["theta_evals_own"] - out[1]["shard"]["theta_evals_own"]) <= sh["theta_rounds"]
     if mcnr:
-        # per iteration: one MCNR statistics collective, then (sum, count) per theta evaluation
-        assert calls[0].count(P * P + P + 2) == 2
-        assert set(calls[0]) == {P * P + P + 2, 2}
-        assert calls[0].count(2) >= 2 * 5
+        assert calls[0].count(P * P + P + 2) == 2      # one MCNR statistics collective per iteration
+        assert set(calls[0]) <= {P * P + P + 2, 1, 2, gather}
+        assert calls[0].count(1) + calls[0].count(2) == sh["theta_rounds"] + 2
     else:
-        assert set(calls[0]) == {2}
+        assert set(calls[0]) <= {1, 2, gather}
+        assert calls[0].count(1) + calls[0].count(2) > sh["theta_rounds"] + 2       # + (sum, count) per MCEM evaluation
+
+
+def test_emulated_rank_record_and_replay():
+    """glmmr_mcml_dbg_emulate_world: one rank of an 8-rank job whose peers are copies of itself.  Record (all candidate
+    thetas evaluated here) and replay (rank 0's share only, the rest from the record) must give the same fit, and the
+    replay must evaluate one candidate per round."""
+    from glmmrmcml_amd import api
+    d = synth.geospatial(n=150, seed=9)
+    args = (d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"])
+    kw = dict(mcnr=True, maxiter=2, warmup=15, tol=1e-12, lambda_=0.3, maxsteps=6, target_accept=0.9, seed=4242,
+              chains=8, m=8, maxfun=40)
+    with api.Context(*args) as ctx:
+        ctx.emulate_world(8, 1)
+        rec = ctx.mcml_full(d["start"], **kw)
+        s1 = ctx.shard_stats()
+        urec = ctx.get_u_all()
+        ctx.emulate_world(8, 2)
+        rep = ctx.mcml_full(d["start"], **kw)
+        s2 = ctx.shard_stats()
+        urep = ctx.get_u_all()
+        with pytest.raises(Exception, match="replay ran past its record"):
+            ctx.mcml_optim(d["start"], mcnr=True, maxfun=8)
+        ctx.emulate_world(1, 0)
+    assert np.array_equal(rec["beta"], rep["beta"]) and np.array_equal(rec["theta"], rep["theta"])
+    assert rec["sigma"] == rep["sigma"] and np.array_equal(urec, urep)
+    assert urec.shape == (d["Q"], 64) and np.array_equal(urec[:, :8], urec[:, 56:])     # eight copies of the block
+    rounds = s1["theta_rounds"]
+    assert s1["theta_evals_own"] == rounds                                              # rank 0 owns slot 0 of a round
+    assert s1["theta_evals_all"] <= 2 * 40 and s1["theta_evals_all"] > 4 * rounds       # rounds are mostly full
+    assert s2["theta_rounds"] - rounds == rounds and s2["theta_evals_own"] - s1["theta_evals_own"] == s1["theta_evals_own"]
 
 
 def test_world_gt_1_without_exchange_is_an_error():
@@ -152,3 +202,15 @@ def test_native_rccl_single_rank_group():
     assert st["native"] and st["calls"] >= 4 and st["doubles"] >= 2 * (d["P"] ** 2 + d["P"] + 2)
     assert np.array_equal(got["beta"], base["beta"]) and np.array_equal(got["theta"], base["theta"])
     assert np.array_equal(ug, ub) and np.isfinite(ll)
+    # the batch theta-step on the same 1-rank communicator: the samples go through ncclAllGather, the candidate values
+    # through ncclAllReduce; run to convergence it finds the sequential optimiser's theta
+    kw2 = dict(kw); kw2.pop("maxfun")
+    with api.Context(*args) as ctx:
+        seq = ctx.mcml_full(d["start"], **kw2)
+    with api.Context(*args) as ctx:
+        ctx.comm_init_rccl(api.rccl_unique_id(), 0, 1)
+        bat = ctx.mcml_full(d["start"], theta_batch=4, **kw2)
+        sh = ctx.shard_stats()
+        assert np.array_equal(ctx.get_u_all(), ctx.get_u())
+    assert sh["gathers"] == 2 and sh["theta_rounds"] >= 6 and sh["theta_evals_all"] == sh["theta_evals_own"]
+    assert np.abs(bat["theta"] - seq["theta"]).max() < 2e-6 and np.abs(bat["beta"] - seq["beta"]).max() < 2e-6

@@ -111,3 +111,107 @@ def test_fd_hessian_is_optimhess():
     _lib.check(L.glmmr_mcml_dbg_fd_hessian(cb3, None, n, x.ctypes.data_as(dp), C.c_double(1e-4), 1,
                                            lo.ctypes.data_as(dp), up.ctypes.data_as(dp), H.ctypes.data_as(dp)))
     assert np.all(np.isfinite(H))
+
+
+# ---------------------------------------------------------------- the batch schedule (csrc/optim.h bobyqa_batch)
+# What the theta-step of a chain-sharded job runs (drivers.hip d_optim_sharded): `width` candidates per round, one per
+# rank.  No reference counterpart (the reference is one process); the contract is the sequential optimiser's: the same
+# optimum of the same objective -- in far fewer ROUNDS than the sequential run needs evaluations.
+def _bobyqa_batch(fun, x0, width, lower=None, upper=None, rhobeg=0.0, rhoend=0.0, maxfun=0):
+    from glmmrmcml_amd import _lib
+    L = _lib.lib()
+    n = len(x0)
+    calls = []
+
+    def cb(xp, nn, user):
+        x = np.array([xp[i] for i in range(nn)])
+        calls.append(x)
+        return float(fun(x))
+    cbk = OBJ(cb)
+    x0 = np.asarray(x0, float); out = np.zeros(n); f = C.c_double(); nf = C.c_int(); rd = C.c_int()
+    lo = None if lower is None else np.asarray(lower, float)
+    up = None if upper is None else np.asarray(upper, float)
+    rc = L.glmmr_mcml_dbg_bobyqa_batch(cbk, None, n, x0.ctypes.data_as(dp),
+                                       None if lo is None else lo.ctypes.data_as(dp),
+                                       None if up is None else up.ctypes.data_as(dp),
+                                       C.c_double(rhobeg), C.c_double(rhoend), maxfun, width,
+                                       out.ctypes.data_as(dp), C.byref(f), C.byref(nf), C.byref(rd))
+    _lib.check(rc)
+    return out, f.value, nf.value, rd.value, calls
+
+
+def _mvn_objective(Q=120, m=24, seed=5):
+    """-(1/m) sum_j log N(u_j; 0, D(theta)), D = theta_0 exp(-d / theta_1): the theta-step's objective
+    (mcmldmatrix.h:23-41) in numpy, samples drawn at theta = (0.25, 0.1)"""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(size=(Q, 2))
+    dist = np.sqrt(((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1))
+    U = np.linalg.cholesky(0.25 * np.exp(-dist / 0.1)) @ rng.standard_normal((Q, m))
+
+    def f(th):
+        try:
+            Lc = np.linalg.cholesky(th[0] * np.exp(-dist / th[1]))
+        except np.linalg.LinAlgError:
+            return 1e300
+        z = sla.solve_triangular(Lc, U, lower=True)
+        return -(-0.5 * Q * np.log(2 * np.pi) - np.log(np.diag(Lc)).sum() - 0.5 * (z * z).sum() / m)
+    return f
+
+
+@pytest.mark.parametrize("width", [1, 2, 3, 4, 8, 16])
+def test_batch_schedule_finds_the_sequential_optimum(width):
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 5):
+        A = rng.normal(size=(n, n)); A = A @ A.T + n * np.eye(n)
+        xs = rng.normal(size=n)
+        x, f, nf, rounds, _ = _bobyqa_batch(lambda x: 0.5 * (x - xs) @ A @ (x - xs) + 3.0, xs + 1.0, width)
+        assert np.abs(x - xs).max() < 2e-6 and abs(f - 3.0) < 1e-10, (n, width)
+        assert rounds * width >= nf > 0 and (width == 1 or rounds < nf)
+    ros = lambda x: 100 * (x[1] - x[0] ** 2) ** 2 + (1 - x[0]) ** 2
+    x, f, nf, rounds, calls = _bobyqa_batch(ros, [-1.2, 1.0], width, lower=[-2, -2], upper=[0.5, 2], rhoend=1e-8)
+    assert abs(x[0] - 0.5) < 1e-7 and abs(x[1] - 0.25) < 1e-5
+    allx = np.array(calls)
+    assert allx[:, 0].max() <= 0.5 and allx.min() >= -2          # never evaluates outside the bounds
+    x, f, nf, rounds, _ = _bobyqa_batch(lambda x: (x[0] - 0.3) ** 2, [1.0], width, lower=[1e-6], upper=[np.inf])
+    assert abs(x[0] - 0.3) < 1e-6
+
+
+def test_batch_schedule_on_the_theta_step_objective():
+    """the MVN objective over log(theta) as d_optim_sharded runs it (rhobeg 0.25, rhoend 1e-7): same optimum as the
+    sequential optimiser over theta, a fraction of its sequential depth, identical on every rank (deterministic)"""
+    f = _mvn_objective()
+    g = lambda z: f(np.exp(z))
+    xs, fs, nfs, _ = _bobyqa(f, [0.4, 0.15], lower=[1e-6] * 2, upper=[np.inf] * 2)
+    for start in ([0.4, 0.15], [0.25, 0.1], [0.1, 0.3]):
+        for width in (2, 8):
+            z, fb, nf, rounds, calls = _bobyqa_batch(g, np.log(start), width, lower=[np.log(1e-6)] * 2,
+                                                     upper=[np.inf] * 2, rhobeg=0.25, rhoend=1e-7)
+            assert abs(fb - fs) < 1e-9 * abs(fs) and np.abs(np.exp(z) - xs).max() < 2e-6 * np.abs(xs).max(), (start, width)
+            if width == 8:
+                assert rounds <= 20 and rounds < nfs / 3, (rounds, nfs)        # sequential depth: 10-16 vs ~60-100
+            z2, fb2, nf2, rounds2, calls2 = _bobyqa_batch(g, np.log(start), width, lower=[np.log(1e-6)] * 2,
+                                                          upper=[np.inf] * 2, rhobeg=0.25, rhoend=1e-7)
+            assert np.array_equal(z, z2) and nf == nf2 and all(np.array_equal(a, b) for a, b in zip(calls, calls2))
+
+
+def test_batch_schedule_under_a_fixed_budget():
+    """bench.py's theta-step budget (40 evaluations): eight candidates per round = five or six rounds, and the
+    objective reached is no worse than what the sequential optimiser reaches with the same 40 evaluations"""
+    f = _mvn_objective()
+    g = lambda z: f(np.exp(z))
+    fopt = _bobyqa(f, [0.25, 0.1], lower=[1e-6] * 2, upper=[np.inf] * 2)[1]
+    for start in ([0.25, 0.1], [0.3, 0.12], [0.2, 0.08]):
+        _, fseq, nfs, _ = _bobyqa(f, start, lower=[1e-6] * 2, upper=[np.inf] * 2, maxfun=40)
+        z, fb, nf, rounds, _ = _bobyqa_batch(g, np.log(start), 8, lower=[np.log(1e-6)] * 2, upper=[np.inf] * 2,
+                                             rhobeg=0.25, rhoend=1e-7, maxfun=40)
+        assert nf <= 40 and rounds <= 7
+        assert fb - fopt <= max(fseq - fopt, 1e-6), (start, fb - fopt, fseq - fopt)
+
+
+def test_batch_objective_failure_and_nan():
+    # NaN objective values are "+inf" as in the sequential optimiser; maxfun inside the initial design still answers
+    x, f, nf, rounds, _ = _bobyqa_batch(lambda x: np.nan if x[0] < 0 else (x[0] - 1) ** 2 + x[1] ** 2, [2.0, 1.0], 4)
+    assert np.abs(x - [1, 0]).max() < 1e-5
+    x, f, nf, rounds, _ = _bobyqa_batch(lambda x: float(np.sum(x ** 2)), [2.0, -1.0], 4, maxfun=3)
+    assert nf <= 4 and np.isfinite(f)

@@ -69,11 +69,13 @@ struct BandPlan {
             return;
         }
         // Streamed: walk the bands in order and fill one workgroup after another up to a cost cap.  Cost in
-        // half K tiles: 2 per K tile + OVH per item (ring fill, barrier, epilogue or partial store: measured
-        // ~2.5 K tiles' worth, so a workgroup that sweeps up several short bands gets fewer K tiles).  The cap is
+        // half K tiles: 2 per K tile + OVH per item (ring fill, barrier, epilogue or partial store).  Per-workgroup
+        // phase stamps (scripts/band_clocks.py 5000 128 1 48) put a second item at about one K tile: with OVH = 5
+        // the two-item workgroups ended 8 us before the single-item ones and only 249 of 256 CUs were used at
+        // n = 5000, 128 chains; OVH = 3 fills all 256 and the longest run drops from 21 to 20 K tiles.  The cap is
         // the smallest one whose greedy fill needs at most nwg workgroups (bisection).
         int nwg = target_wg / gn; if (nwg < 1) nwg = 1;
-        constexpr long OVH = 5;
+        constexpr long OVH = 3;
         auto fill = [&](long cap, bool emit) -> int {
             int used = 1; long room = cap;
             if (emit) wg_ptr.push_back(0);

@@ -139,11 +139,16 @@ extern "C" int glmmr_mcml_dbg_band_clocks(int M, int N, int iters, int mode, dou
         return MCML_ENODEVICE;
     }
     hipStream_t s = nullptr;
+    if (getenv("GLMMR_MCML_DBG_STREAM")) MCML_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     std::vector<double> hA((size_t)M * M, 0.0), hB((size_t)M * N);
     uint64_t x = 88172645463325252ULL;
     auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (double)(x >> 11) / 9007199254740992.0 * 2 - 1; };
-    for (int j = 0; j < M; ++j) for (int i = j; i < M; ++i) hA[i + (size_t)j * M] = rnd();
-    for (auto& v : hB) v = rnd();
+    // GLMMR_MCML_DBG_DATA=const: every entry 1.0 instead of random mantissas (MFMA power draw depends on the data)
+    const bool cst = getenv("GLMMR_MCML_DBG_DATA") && !strcmp(getenv("GLMMR_MCML_DBG_DATA"), "const");
+    // =decay: entries fall off away from the diagonal like a Cholesky factor of an exponential covariance
+    const bool dec = getenv("GLMMR_MCML_DBG_DATA") && !strcmp(getenv("GLMMR_MCML_DBG_DATA"), "decay");
+    for (int j = 0; j < M; ++j) for (int i = j; i < M; ++i) hA[i + (size_t)j * M] = cst ? 1.0 : dec ? rnd() * std::exp(-(double)(i - j) / 40.0) : rnd();
+    for (auto& v : hB) v = cst ? 1.0 : rnd();
     DevMat dA, dB, dC;
     MCML_TRY(dA.alloc(M, M, 32));
     MCML_HIP(hipMemset(dA.d(), 0, sizeof(double) * (size_t)dA.ld * dA.cols_alloc));
@@ -164,6 +169,57 @@ extern "C" int glmmr_mcml_dbg_band_clocks(int M, int N, int iters, int mode, dou
     plan.reset(M, M, hk);
     const double tiles = (double)plan.tiles;
     EpiAxpby epi{dC.d(), dC.ld, 1.0, 0.0};
+    if (mode < 0) {
+        // the sampler's own instantiation (no experiment branches, no clock reads): what rocprofv3 should look at
+        for (int i = 0; i < 3; i++)
+            MCML_TRY((launch_gemm_band<EpiAxpby, false>(s, plan, N, dA.d(), dA.ld, dB.d(), dB.ld, epi)));
+        hipEvent_t f0, f1;
+        MCML_HIP(hipEventCreate(&f0));
+        MCML_HIP(hipEventCreate(&f1));
+        MCML_HIP(hipEventRecord(f0, s));
+        for (int i = 0; i < iters; i++)
+            MCML_TRY((launch_gemm_band<EpiAxpby, false>(s, plan, N, dA.d(), dA.ld, dB.d(), dB.ld, epi)));
+        MCML_HIP(hipEventRecord(f1, s));
+        MCML_HIP(hipEventSynchronize(f1));
+        float fms = 0;
+        MCML_HIP(hipEventElapsedTime(&fms, f0, f1));
+        out3[0] = fms / iters; out3[1] = 0;
+        out3[2] = 2.0 * 80.0 * 32.0 * tiles * N / (fms / iters * 1e-3) / 1e12;
+        (void)hipEventDestroy(f0);
+        (void)hipEventDestroy(f1);
+        return MCML_OK;
+    }
+    if (mode & 16) {
+        // phase stamps of every workgroup of ONE launch (dgemm_band.h), printed as offsets from the earliest start
+        BandPlanDev* d = nullptr;
+        MCML_TRY(plan.device_plan((N + BD_BN - 1) / BD_BN, s, &d));
+        const int nb = d->nwg * d->gn;
+        DevBuf st;
+        MCML_TRY(st.ensure(sizeof(unsigned long long) * (8 + 8 * (size_t)nb)));
+        for (int rep = 0; rep < 3; ++rep) {
+            MCML_HIP(hipMemset(st.p, 0, sizeof(unsigned long long) * (8 + 8 * (size_t)nb)));
+            MCML_TRY((launch_gemm_band<EpiAxpby, true>(s, plan, N, dA.d(), dA.ld, dB.d(), dB.ld, epi, st.as<unsigned long long>(), mode)));
+            MCML_HIP(hipDeviceSynchronize());
+        }
+        std::vector<unsigned long long> h(8 + 8 * (size_t)nb);
+        MCML_HIP(hipMemcpy(h.data(), st.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ULL;
+        for (int w = 0; w < nb; ++w) if (h[8 + 8 * w] && h[8 + 8 * w] < t0) t0 = h[8 + 8 * w];
+        double mx[5] = {0, 0, 0, 0, 0}, sm[5] = {0, 0, 0, 0, 0};
+        for (int w = 0; w < nb; ++w)
+            for (int i = 0; i < 5; ++i) { double v = (double)(h[8 + 8 * w + i] - t0) * 0.01; sm[i] += v; if (v > mx[i]) mx[i] = v; }
+        printf("band stamps (us from the first workgroup's start; %d workgroups, mean / max):\n", nb);
+        const char* nm[5] = {"start", "ring filled", "K loop done", "epilogue issued", "end"};
+        for (int i = 0; i < 5; ++i) printf("  %-16s %7.2f / %7.2f\n", nm[i], sm[i] / nb, mx[i]);
+        if (mode & 32) for (int w = 0; w < nb; ++w) {
+            printf("  wg %3d:", w);
+            for (int i = 0; i < 5; ++i) printf(" %7.2f", (double)(h[8 + 8 * w + i] - t0) * 0.01);
+            printf("\n");
+        }
+        fflush(stdout);
+        out3[0] = out3[1] = out3[2] = 0;
+        return MCML_OK;
+    }
     for (int i = 0; i < 3; i++)
         MCML_TRY((launch_gemm_band<EpiAxpby, true>(s, plan, N, dA.d(), dA.ld, dB.d(), dB.ld, epi)));
     hipEvent_t e0, e1;

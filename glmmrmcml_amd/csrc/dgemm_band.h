@@ -20,6 +20,13 @@
 //     piece stored as a raw accumulator tile (in register order: 512-byte coalesced stores) and
 //     k_band_reduce sums the pieces IN K ORDER and applies the same epilogue functor -- a
 //     fixed-order two-stage reduction, bit-reproducible for a given (operand, chain count).
+//     (Measured dead end, round 3: folding the second stage into the piece that ARRIVES LAST -- write-through
+//     (sc1) tile stores, one relaxed agent-scope counter per band, sc1 loads by the last arriver -- is correct
+//     (parity suite green) but no faster: 80.4 / 82.7 us against 76.7 / 82.4 us per forward / backward product at
+//     n = 5000 with 128 chains, 44.5 / 47.9 against 39.2 / 41.7 us at n = 2000 with 256 -- one workgroup per band
+//     reads up to eight 80 KB pieces back from memory in dependent batches, where this kernel spreads a band
+//     over four workgroups and finds the pieces in L2.  With agent-scope release / acquire fences instead of
+//     write-through stores every wave issues a buffer_wbl2, a walk over the XCD's whole L2: 160 us per product.)
 //
 // Same direct-to-LDS machinery as dgemm_dlds.h: 80 x 128 tile, 8 waves (each a 80 x 16 strip =
 // 5 x 1 v_mfma_f64_16x16x4 tiles), K step 32, 3-stage LDS ring (156 KB), counted vmcnt + raw
@@ -218,7 +225,16 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
         else if (tiles == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    const int mode = DBG ? bp.mode : 0;
+    const int mode = DBG ? (bp.mode & 15) : 0;
+    // DBG, mode bit 16: every workgroup leaves 100 MHz real-time stamps of its phases at clocks[8 + 8 * bid ..]:
+    // [start, first ring stages landed, K loop of the first item done, its epilogue / partial store issued, end]
+    const bool stamps = DBG && (bp.mode & 16) && bp.clocks;
+    auto stamp = [&](int i) {
+        if constexpr (DBG)
+            if (stamps && tid == 0) bp.clocks[8 + 8 * (size_t)blockIdx.x + i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+    bool first_item = true;
     // `pre`: the first ring stages of the item about to start are already in flight -- they were issued BEFORE the
     // previous item's epilogue (the ring is free once every wave has passed the last barrier of a K loop), so the
     // fill's memory latency runs under the epilogue's loads and stores instead of after them
@@ -241,6 +257,7 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
             if (!pre) { issued = 0; for (; issued < BD_STAGES - 1 && issued < nk; ++issued) issue(issued); }
             wait_leave(issued - 1);
             __builtin_amdgcn_s_barrier();
+            if (first_item) stamp(1);
             int st = 0;
             double ra[2][5], rb[2];
             bd_read<0>(ra[0], rb[0], aoff, boff);
@@ -335,6 +352,7 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
                 st = st + 1; if (st >= BD_STAGES) st = 0;
             }
         }
+        if (first_item) stamp(2);
         ++it;
         pre = false;
         if (it < it1) {
@@ -357,9 +375,12 @@ __global__ __launch_bounds__(512) void dgemm_band_kernel(BandP bp, Epi epi)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) P[(i * 4 + r) * 64] = acc[i][0][r];
         }
+        if (first_item) { stamp(3); first_item = false; }
         // without a prefetch the next item's first LDS-DMA may overwrite a stage another wave is still reading
         if (!pre) __builtin_amdgcn_s_barrier();
     }
+    if constexpr (DBG)
+        if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(4); }
     if constexpr (DBG)
         if (bp.clocks && blockIdx.x == 0 && tid == 0) {
             atomicAdd(bp.clocks, __builtin_amdgcn_s_memtime() - t0c);

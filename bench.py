@@ -95,6 +95,70 @@ def cpu_baseline(d, cfg, budget_props=30):
     }
 
 
+HBM_PEAK_TBS = 8.0                # MI355X HBM3E (MI355X_MICROARCH.md)
+
+
+def other_configs(api, synth, stream, iters=3):
+    """BASELINE configs 2, 4 and 5 on this GPU, `iters` whole mcml_full iterations each after one untimed iteration
+    (HMC warm-up 100 + 1 draw per chain, <= 10 leapfrog steps, optimiser budget 40): ms per iteration, simlik evals/s and
+    the roofline fraction of the configuration's dominant kernel pair (the two HMC products), timed with HIP events on
+    the library's stream like the headline line.  Config 5 also times mcml_hess (its 'Hessian SE')."""
+    import torch
+    out = {}
+    specs = [("cfg2", "gaussian geospatial n=Q=2000 fexp, MCEM, m=256", lambda: synth.geospatial(2000, seed=1), 256, False, 5.0),
+             ("cfg4", "binomial stepped-wedge 40 cl x 8 t x 50 ind (n=16000, Q=320, gr*ar1 blocks of 8), MCNR, m=512",
+              lambda: synth.stepped_wedge(40, 8, 50), 512, True, 0.5),
+             ("cfg5", "poisson longitudinal 2000 subjects x 10 visits (n=20000, Q=22000, diagonal D), MCNR, m=1024",
+              lambda: synth.longitudinal(2000, 10), 1024, True, 0.5)]
+    for key, desc, gen, m, mcnr, lam in specs:
+        try:
+            d = gen()
+            with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"],
+                             stream=stream) as ctx:
+                kw = dict(mcnr=mcnr, m=m, warmup=100, tol=0.0, verbose=False, lambda_=lam, maxsteps=10, target_accept=0.9,
+                          seed=7, chains=m, maxfun=40)
+                ctx.mcml_full(d["start"], maxiter=1, **kw)
+                ctx.profile(enable=True, reset=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r = ctx.mcml_full(d["start"], maxiter=iters, **kw)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                p = ctx.profile(enable=False)
+                nl = p["fwd_n"] + p["bwd_n"]
+                ks = (p["fwd_ms"] + p["bwd_ms"]) * 1e-3
+                n, Q = d["n"], d["Q"]
+                if p["operator"] == "sparse":
+                    # algorithmic bytes per product (DESIGN 5.4): forward 8 (nC [S] + QC [X]), backward 8 (nC + 4 QC)
+                    bytes_alg = (p["fwd_n"] * 8.0 * (n * m + Q * m) + p["bwd_n"] * 8.0 * (n * m + 4 * Q * m))
+                    roof = {"bound": "hbm", "kernel": "k_cm_forward / k_cm_backward (sparse ZL operator, chain-major)",
+                            "achieved": bytes_alg / ks / 1e12 if nl else 0.0, "peak": HBM_PEAK_TBS, "unit": "TB/s"}
+                else:
+                    ex = p["fwd_flops"] * p["fwd_n"] + p["bwd_flops"] * p["bwd_n"]
+                    roof = {"bound": "mfma", "kernel": "dgemm_band_kernel + k_band_reduce (HMC products, FP64 MFMA)",
+                            "achieved": ex / ks / 1e12 if nl else 0.0, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+                roof["frac"] = roof["achieved"] / roof["peak"]
+                roof["avg_launch_us"] = ks / max(1, nl) * 1e6
+                roof["share_of_iteration"] = ks / max(1, nl) * (p["fwd_n_all"] + p["bwd_n_all"]) / dt
+                rec = {"workload": desc, "ms_per_iter": dt / iters * 1e3, "evals_per_s": m * iters / dt, "iters": iters,
+                       "roofline": roof, "beta": [float(x) for x in r["beta"]], "theta": [float(x) for x in r["theta"]],
+                       "sigma": float(r["sigma"]), "accept_rate": r["accept_rate"]}
+                rec["fit_ok"] = bool(np.all(np.isfinite(r["beta"])) and np.all(np.isfinite(r["theta"])) and
+                                     np.all(np.asarray(r["theta"]) > 0) and
+                                     np.all(np.abs(np.asarray(r["theta"]) - d["theta"]) < 0.6 * np.maximum(d["theta"], 0.15)))
+                if key == "cfg5":
+                    start = np.r_[r["beta"], r["theta"], 1.0]
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    H = ctx.mcml_hess(start, tol=1e-4)
+                    torch.cuda.synchronize()
+                    rec["mcml_hess_ms"] = (time.perf_counter() - t0) * 1e3
+                    rec["fit_ok"] = bool(rec["fit_ok"] and np.all(np.isfinite(H)))
+                out[key] = rec
+        except Exception as e:                       # never blocks the headline number
+            out[key] = {"workload": desc, "error": repr(e)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +172,7 @@ def main():
                     help="N > 1: the library's own RCCL communicator (default) or the torch.distributed hook")
     ap.add_argument("--dense-z", action="store_true", help="dense (non-identity) Z: ZL dense, no zero skipping")
     ap.add_argument("--as-rank-of", type=int, default=0, help="time one rank of an N-rank job on one GPU (peers emulated)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 2, 4, 5 after the timed region")
     args = ap.parse_args()
 
     import torch
@@ -216,6 +281,16 @@ def main():
         tdist.all_reduce(tt, op=tdist.ReduceOp.MAX)
         dt = float(tt.item())
     prof = ctx.profile(enable=False)
+    # what was computed (outside the timed region): the fit after `steps` iterations and the theta-step's objective there
+    fit = {"beta": [float(x) for x in res["beta"]], "theta": [float(x) for x in res["theta"]], "sigma": float(res["sigma"])}
+    if not emu:
+        fit["mvn_ll_at_theta"] = float(ctx.mvn_ll(res["theta"]))
+    th = np.asarray(res["theta"])
+    fit_ok = bool(np.all(np.isfinite(res["beta"])) and np.all(np.isfinite(th)) and np.isfinite(res["sigma"]) and
+                  0.1 < th[0] < 0.6 and 0.03 < th[1] < 0.3 and 0.7 < res["sigma"] < 1.3 and 0.0 < res["beta"][0] < 2.0 and
+                  np.isfinite(fit.get("mvn_ll_at_theta", 0.0)))
+    if args.n == CFG["n"] and not args.dense_z:
+        assert fit_ok, "the timed iterations left the band round the generating values (theta 0.25, 0.1; sigma 1; beta 1): %r" % (fit,)
     shard1 = ctx.shard_stats()
     shard = {k: shard1[k] - shard0[k] for k in shard1}
     assert res["iters"] == args.steps, "timed region ran %d iterations, not %d" % (res["iters"], args.steps)
@@ -261,7 +336,8 @@ def main():
                                       % (shard["theta_rounds"], shard["theta_evals_own"], shard["theta_evals_all"],
                                          shard["gathers"], 8e-6 * shard["gather_doubles"] / max(1, shard["gathers"])))
                                      if shard["theta_rounds"] else "sequential BOBYQA on this GPU, %d evaluations per step" % cfg["theta_maxfun"],
-                       "accept_rate": res["accept_rate"], "leapfrog_steps_last_iter": res["leapfrog_total"]},
+                       "accept_rate": res["accept_rate"], "leapfrog_steps_last_iter": res["leapfrog_total"],
+                       "fit": fit, "fit_ok": fit_ok},
             "roofline": {"bound": "mfma",
                          "kernel": "dgemm_%s_kernel (HMC forward / backward n x Q x C product, FP64 MFMA)"
                                    % ("band" if prof["operator"] == "banded" else "dlds"),
@@ -292,6 +368,9 @@ def main():
             except Exception as e:           # the baseline never blocks the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "simlik evals/s", "cores": 0, "kind": "port",
                                         "sample": "failed: %r" % (e,)}
+        if world == 1 and not emu and not args.no_other_configs and args.n == CFG["n"] and args.chains <= 0 and not args.dense_z:
+            ctx.close()
+            line["other_configs"] = other_configs(api, synth, stream)
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:

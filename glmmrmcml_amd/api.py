@@ -281,6 +281,24 @@ class Context:
     def npar(self):
         return _lib.lib().glmmr_mcml_ctx_npar(self._h)
 
+    def theta_log(self, enable=None, last=None):
+        """test hook: the theta-step's objective evaluations, rows (theta..., log-likelihood); enable True clears + starts"""
+        w = self.npar() + 1
+        n = C.c_int()
+        _lib.check(_lib.lib().glmmr_mcml_dbg_theta_log(self._h, -1, None, 0, C.byref(n)))
+        rows = n.value if last is None else min(int(last), n.value)
+        out = np.zeros((rows, w))
+        _lib.check(_lib.lib().glmmr_mcml_dbg_theta_log(self._h, -1 if enable is None else int(bool(enable)),
+                                                       _p(out) if rows else None, rows, C.byref(n)))
+        return out
+
+    def last_kernels(self):
+        """kernel family of the sampler's last (forward, backward) product"""
+        names = {-1: None, 0: "skinny", 1: "band", 2: "dlds", 3: "reg", 4: "sparse"}
+        f = C.c_int(); b = C.c_int()
+        _lib.check(_lib.lib().glmmr_mcml_ctx_last_kernels(self._h, C.byref(f), C.byref(b)))
+        return names[f.value], names[b.value]
+
     def mcml_optim(self, start, trace=0, mcnr=False, maxfun=0, theta_batch=0):
         start = _f(start).ravel(); R = self.npar()
         b = np.zeros(self.P); t = np.zeros(R); sg = C.c_double()

@@ -153,6 +153,30 @@ extern "C" int glmmr_mcml_get_u_all(glmmr_mcml_ctx* h, double* u, int ldu, int* 
     return download_matrix(u, ldu, c.Uall.d(), c.Uall.ld, c.Q, c.Uall.cols, c.stream);
 }
 
+extern "C" int glmmr_mcml_dbg_theta_log(glmmr_mcml_ctx* h, int enable, double* out, int cap_rows, int* nrows)
+{
+    MCML_REQUIRE(h, "theta_log: null context");
+    Ctx& c = h->c;
+    const int w = c.cov.npar + 1;
+    const int have = (int)(c.theta_log.size() / (size_t)w);
+    if (nrows) *nrows = have;
+    if (out) {
+        const int take = have < cap_rows ? have : cap_rows;       // the LAST `take` rows
+        memcpy(out, c.theta_log.data() + (size_t)(have - take) * w, sizeof(double) * (size_t)take * w);
+        if (nrows) *nrows = take;
+    }
+    if (enable >= 0) { c.theta_log_on = enable != 0; if (enable) c.theta_log.clear(); }
+    return MCML_OK;
+}
+
+extern "C" int glmmr_mcml_ctx_last_kernels(glmmr_mcml_ctx* h, int* fwd, int* bwd)
+{
+    MCML_REQUIRE(h, "last_kernels: null context");
+    if (fwd) *fwd = h->c.last_kernel[0];
+    if (bwd) *bwd = h->c.last_kernel[1];
+    return MCML_OK;
+}
+
 extern "C" int glmmr_mcml_ctx_shard_stats(glmmr_mcml_ctx* h, long long* out6)
 {
     MCML_REQUIRE(h && out6, "shard_stats: null argument");

@@ -16,6 +16,9 @@ constexpr int SMALL_BLOCK = 32;  // blocks up to this size are factorised one wa
 // all-reduces the buffer with torch.distributed (backend "nccl" = RCCL).
 typedef int (*reduce_fn)(void* user, double* dev_buf, int n);
 
+// kernel family that served an HMC product (glmmr_mcml_ctx_last_kernels)
+enum { KERNEL_SKINNY = 0, KERNEL_BAND = 1, KERNEL_DLDS = 2, KERNEL_REG = 3, KERNEL_SPARSE = 4 };
+
 struct HmcState {
     int C = 0;                  // chains resident
     int Cw = 0;                 // columns the two products and the log-density kernels process (= C; the No-U-Turn
@@ -150,6 +153,7 @@ struct Ctx {
     int n_small = 0, n_diag_rows = 0;
 
     // sampler
+    int last_kernel[2] = {-1, -1};   // kernel family of the last forward / backward product (KERNEL_*)
     HmcState hmc;
     NutsState nuts;
     KernelProf prof;
@@ -165,6 +169,8 @@ struct Ctx {
     // samples change.  The theta-step of a sharded job reads these (drivers.hip::d_optim).
     DevMat Uall;
     bool uall_valid = false;
+    bool theta_log_on = false;          // tests: every MVN objective evaluation as (theta..., log-likelihood)
+    std::vector<double> theta_log;
     long long theta_rounds = 0, theta_evals_own = 0, theta_evals_all = 0;   // sharded theta-step: exchanges, evaluations here / everywhere
     // rank emulation on one GPU (bench.py --as-rank-of N, include/glmmr_mcml_c.h glmmr_mcml_dbg_emulate_world): the
     // other ranks are copies of this one -- a sum is `emu_world` times the local value, a gather `emu_world` copies of

@@ -18,6 +18,25 @@ extern "C" int glmmr_mcml_dbg_dgemm(int M, int N, int K, const double* A, int ld
     }
     hipStream_t s = nullptr;
     DevMat dA, dB, dC;
+    if (force_tile == 40) {
+        // the sampler's dense direct-to-LDS kernel (dgemm_dlds.h: dgemm_dlds_asm_kernel unless GLMMR_MCML_DLDS picks a
+        // compiler-scheduled variant), with the operand contract the sampler meets: zero columns / rows up to the
+        // next multiple of 32 in K
+        MCML_REQUIRE(!b_nmajor && !lower_only, "dbg_dgemm: the direct-to-LDS kernel takes a K-major B and all tiles");
+        const int kpad = round_up(K, 32);
+        MCML_TRY(dA.alloc(M, K, 32));
+        MCML_HIP(hipMemset(dA.d(), 0, sizeof(double) * (size_t)dA.ld * dA.cols_alloc));
+        MCML_HIP(hipMemcpy2D(dA.d(), sizeof(double) * dA.ld, A, sizeof(double) * lda, sizeof(double) * M, K, hipMemcpyHostToDevice));
+        MCML_TRY(dB.alloc(kpad, N));
+        MCML_HIP(hipMemset(dB.d(), 0, sizeof(double) * (size_t)dB.ld * N));
+        MCML_HIP(hipMemcpy2D(dB.d(), sizeof(double) * dB.ld, B, sizeof(double) * ldb, sizeof(double) * K, N, hipMemcpyHostToDevice));
+        MCML_TRY(upload_matrix(dC, C, M, N, ldc, s));
+        MCML_REQUIRE(dlds_applicable(M, N, K, dA.d(), dA.ld, dA.cols_alloc, dB.d(), dB.ld), "dbg_dgemm: operands do not meet the direct-to-LDS contract");
+        EpiAxpby epi2{dC.d(), dC.ld, alpha, beta};
+        MCML_TRY(launch_gemm_dlds(s, M, N, K, dA.d(), dA.ld, dB.d(), dB.ld, epi2));
+        MCML_TRY(download_matrix(C, ldc, dC.d(), dC.ld, M, N, s));
+        return MCML_OK;
+    }
     MCML_TRY(upload_matrix(dA, A, M, K, lda, s));
     if (b_nmajor) MCML_TRY(upload_matrix(dB, B, N, K, ldb, s));
     else MCML_TRY(upload_matrix(dB, B, K, N, ldb, s));

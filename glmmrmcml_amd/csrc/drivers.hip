@@ -56,6 +56,7 @@ static int eval_mvn(Ctx& c, const double* theta, double* logl)
     double tot[2] = {s, (double)c.mcols};
     MCML_TRY(allreduce_host(c, tot, 2));
     *logl = tot[0] / tot[1];
+    if (c.theta_log_on) { c.theta_log.insert(c.theta_log.end(), theta, theta + c.cov.npar); c.theta_log.push_back(*logl); }
     return MCML_OK;
 }
 
@@ -108,6 +109,7 @@ struct McmlOptim {
                 else if (rc != MCML_OK) { vals[j] = NAN; if (first_rc == MCML_OK) first_rc = rc; }
                 else vals[j] = -1 * (sum / mall);
                 if (mine) ++c.theta_evals_own;
+                if (c.theta_log_on && rc == MCML_OK) { c.theta_log.insert(c.theta_log.end(), th.begin(), th.end()); c.theta_log.push_back(sum / mall); }
             }
             c.theta_rounds += 1; c.theta_evals_all += nc;
             if (!emu) MCML_TRY(allreduce_host(c, vals.data(), nc));      // every slot is zero on all ranks but its owner

@@ -465,12 +465,20 @@ static int hmc_forward_launch(Ctx& c, const double* X, int ldx, const Epi& epi)
 {
     HmcState& h = c.hmc;
     // at most 16 chains (chains = 1: the reference's layout; the tail of a NUTS doubling): an HBM-bound stream, not an MFMA tile
-    if (use_skinny() && skinny_applicable(c.plan_fwd, c.n, c.Q, h.Cw, c.ZL.ld))
+    // c.last_kernel[]: which kernel family served the product (tests assert the path they mean to compare)
+    if (use_skinny() && skinny_applicable(c.plan_fwd, c.n, c.Q, h.Cw, c.ZL.ld)) {
+        c.last_kernel[0] = KERNEL_SKINNY;
         return launch_skinny(c.stream, c.plan_fwd, h.Cw, c.ZL.d(), c.ZL.ld, X, ldx, epi);
-    if (c.band_fwd && dlds_applicable(c.n, h.Cw, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
+    }
+    if (c.band_fwd && dlds_applicable(c.n, h.Cw, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx)) {
+        c.last_kernel[0] = KERNEL_BAND;
         return launch_gemm_band(c.stream, c.plan_fwd, h.Cw, c.ZL.d(), c.ZL.ld, X, ldx, epi);
-    if (use_dlds() && dlds_applicable(c.n, h.Cw, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx))
+    }
+    if (use_dlds() && dlds_applicable(c.n, h.Cw, c.Q, c.ZL.d(), c.ZL.ld, c.ZL.cols_alloc, X, ldx)) {
+        c.last_kernel[0] = KERNEL_DLDS;
         return launch_gemm_dlds(c.stream, c.n, h.Cw, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
+    }
+    c.last_kernel[0] = KERNEL_REG;
     return launch_gemm<false>(c.stream, c.n, h.Cw, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
 }
 
@@ -480,6 +488,7 @@ static int hmc_forward(Ctx& c, const double* X, int ldx, double var_par, bool st
     const int slot = c.prof.begin(c.stream, 0, chain);
     int rc;
     if (h.cm) {
+        c.last_kernel[0] = KERNEL_SPARSE;
         const int rpw = CM_FR;
         dim3 grid((c.n + 4 * rpw - 1) / (4 * rpw), (h.Cw + 63) / 64);
         // factored operator: LX = L X first, then the rows of Z gather from LX
@@ -547,17 +556,23 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
                                c.sp.row_end.as<int>(), c.L.d(), c.L.ld, h.ZS.d(), Xs, G, h.R.d(), h.UP.d(), ca.e, ca.steps, s,
                                post, mode);
         rc = (hipGetLastError() == hipSuccess) ? MCML_OK : MCML_EHIP;
+        c.last_kernel[1] = KERNEL_SPARSE;
         c.prof.end(c.stream, slot);
         return rc;
     }
-    if (use_skinny() && skinny_applicable(c.plan_bwd, c.Q, c.n, h.Cw, c.ZLT.ld))
+    if (use_skinny() && skinny_applicable(c.plan_bwd, c.Q, c.n, h.Cw, c.ZLT.ld)) {
+        c.last_kernel[1] = KERNEL_SKINNY;
         rc = launch_skinny(c.stream, c.plan_bwd, h.Cw, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
-    else if (c.band_bwd && dlds_applicable(c.Q, h.Cw, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
+    } else if (c.band_bwd && dlds_applicable(c.Q, h.Cw, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld)) {
+        c.last_kernel[1] = KERNEL_BAND;
         rc = launch_gemm_band(c.stream, c.plan_bwd, h.Cw, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
-    else if (use_dlds() && dlds_applicable(c.Q, h.Cw, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld))
+    } else if (use_dlds() && dlds_applicable(c.Q, h.Cw, c.n, c.ZLT.d(), c.ZLT.ld, c.ZLT.cols_alloc, h.S.d(), h.S.ld)) {
+        c.last_kernel[1] = KERNEL_DLDS;
         rc = launch_gemm_dlds(c.stream, c.Q, h.Cw, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
-    else
+    } else {
+        c.last_kernel[1] = KERNEL_REG;
         rc = launch_gemm<false>(c.stream, c.Q, h.Cw, c.n, c.ZLT.d(), c.ZLT.ld, h.S.d(), h.S.ld, epi);
+    }
     c.prof.end(c.stream, slot);
     return rc;
 }

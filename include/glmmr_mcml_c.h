@@ -213,6 +213,10 @@ int glmmr_mcml_ctx_profile(glmmr_mcml_ctx* ctx, int enable, int reset, double* o
 /* The sampler TIMES one proposal in four (a marker between two dependent launches costs ~2.5 us of idle GPU): out8's
  * launch counts are the timed launches; these are all forward / backward launches since the last reset. */
 int glmmr_mcml_ctx_profile_launches(glmmr_mcml_ctx* ctx, long long* fwd, long long* bwd);
+/* kernel family that served the sampler's last forward / backward product: 0 streamed few-column kernel
+ * (dgemm_skinny.h), 1 banded FP64 MFMA kernel (dgemm_band.h), 2 dense direct-to-LDS MFMA kernel (dgemm_dlds.h),
+ * 3 register-staged MFMA kernel (dgemm_mfma.h), 4 sparse chain-major operator (hmc_cm.h); -1 none yet */
+int glmmr_mcml_ctx_last_kernels(glmmr_mcml_ctx* ctx, int* fwd, int* bwd);
 int glmmr_mcml_ctx_npar(glmmr_mcml_ctx* ctx);
 
 /* The same drivers on a resident context (what bench.py times). */
@@ -306,6 +310,10 @@ int glmmr_mcml_mvn_ll(const int32_t* cov, int cov_rows, const double* data, int 
                       const double* u, int Q, int m, double* out);
 
 /* ---- test hooks (building blocks exposed for tests/ and bench.py only) ---- */
+/* every evaluation of the theta-step's objective on this context as a row (theta_1 .. theta_R, MVN log-likelihood):
+ * enable 1 clears the log and starts it, 0 stops it, -1 leaves it as it is; out (nullable) receives the LAST cap_rows rows
+ * (row-major, R + 1 doubles each), *nrows the number written (or held, when out is null) */
+int glmmr_mcml_dbg_theta_log(glmmr_mcml_ctx* ctx, int enable, double* out, int cap_rows, int* nrows);
 /* One rank of an N-rank job on ONE GPU, for timing what a rank executes when no N-GPU node is at hand (bench.py
  * --as-rank-of N).  The context stays a single process; its peers are emulated as copies of itself: a sum is N times
  * the local value, the sample all-gather N copies of the local block.  mode 1: the candidate thetas of ALL ranks are
@@ -326,7 +334,9 @@ int glmmr_mcml_dbg_la_probe(glmmr_mcml_ctx* ctx, const double* start, int nstart
                             double* beta_out, double* sigma_out);
 int glmmr_mcml_dbg_dgemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb,
                          int b_nmajor, double alpha, double beta, double* C, int ldc,
-                         int lower_only, int force_tile /* -1 = auto */);
+                         int lower_only, int force_tile /* -1 = auto; 0.. tiles of the register-staged kernel; 20..25 the
+                                                           Cholesky's deep-ring kernel; 40 the sampler's dense direct-to-LDS
+                                                           kernel (dgemm_dlds_asm_kernel) */);
 /* mcmlModel::log_prob / log_grad (mcmlmodel.h:138-279) of every column of V (Q x ncols) */
 int glmmr_mcml_dbg_log_prob_grad(glmmr_mcml_ctx* ctx, const double* beta, double var_par, const double* V,
                                  int ncols, double* lp, double* G);

@@ -4,8 +4,9 @@ its short-row form for config 5; diagonal / small-block mvn_ll; MCNR statistics;
 through size-independent properties:
 
   * a chain's draws depend only on (seed, global chain id), not on how many chains run beside it nor
-    on the operator form: the first chains of the full-size sparse run equal a 16-chain run on the
-    DENSE MFMA operator (accept decisions identical, samples 1e-8);
+    on the operator form: the first chains of the full-size sparse run equal a 32-chain run on the
+    dense n x Q operator served by the FP64 MFMA kernels (more than 16 chains: not the streamed
+    few-column products; asserted through last_kernels()) -- accept decisions identical, samples 1e-8;
   * accept probabilities in (0, 1], dual averaging ends near the target rate;
   * mvn_ll at full size equals the closed form for diagonal D (config 5) / the per-block dense
     evaluation by numpy on a subset of blocks scaled up (config 4: blocks are i.i.d. in structure);
@@ -20,7 +21,7 @@ from glmmrmcml_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _sparse_then_dense(d, C, warm, monkeypatch, lam=0.5, ms=10, seed=31, sub=16):
+def _sparse_then_dense(d, C, warm, monkeypatch, lam=0.5, ms=10, seed=31, sub=32):
     from glmmrmcml_amd import api
     args = (d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"])
     monkeypatch.delenv("GLMMR_MCML_ZL", raising=False)
@@ -38,6 +39,7 @@ def _sparse_then_dense(d, C, warm, monkeypatch, lam=0.5, ms=10, seed=31, sub=16)
         ctx.update_L(d["theta"])
         dg2, fl2, pr2 = ctx.hmc_sample(d["beta"], 1.0, warm, sub, lam, ms, 0.9, seed, chains=sub, want_trace=True)
         assert ctx.profile(enable=False)["operator"] != "sparse"
+        assert set(ctx.last_kernels()) <= {"band", "dlds", "reg"}, ctx.last_kernels()      # an MFMA kernel, both ways
         u2 = ctx.get_u()
     monkeypatch.delenv("GLMMR_MCML_ZL", raising=False)
     assert u.shape == (d["Q"], C) and u2.shape == (d["Q"], sub)
@@ -91,7 +93,7 @@ def test_config5_full_size(monkeypatch):
     """Poisson longitudinal, 2000 subjects x 10 visits (n = 20000), Q = 22000 all-diagonal, m = 1024, + mcml_hess"""
     d = synth.longitudinal(2000, 10)
     assert d["n"] == 20000 and d["Q"] == 22000
-    u, ex = _sparse_then_dense(d, 1024, 30, monkeypatch, sub=16)
+    u, ex = _sparse_then_dense(d, 1024, 30, monkeypatch, sub=32)
     # diagonal closed form (mcmldmatrix.h:61-65): variance = theta^2 per gr block
     sd = np.r_[np.full(2000, d["theta"][0]), np.full(20000, d["theta"][1])]
     want = np.mean((-0.5 * np.log(2 * np.pi) - np.log(sd)[:, None] - 0.5 * (u / sd[:, None]) ** 2).sum(0))

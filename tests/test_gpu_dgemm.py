@@ -57,6 +57,28 @@ def test_dgemm_lower_only_leaves_upper_tiles():
     assert np.array_equal(got[0:128, 640:], C0[0:128, 640:])
 
 
+# the sampler's dense direct-to-LDS kernel (dgemm_dlds.h::dgemm_dlds_asm_kernel, the path of a dense non-identity Z with
+# more than 16 chains): force_tile 40, operands padded to the contract the sampler meets
+@pytest.mark.parametrize("M,N,K", [(160, 128, 32), (161, 129, 33), (333, 77, 250), (1000, 256, 999), (80, 17, 16),
+                                   (5000, 1024, 5000)])
+def test_dgemm_dlds_matches_numpy(M, N, K):
+    rng = np.random.default_rng(M + 3 * N + 7 * K)
+    A = rng.normal(size=(M, K)); Bm = rng.normal(size=(K, N)); C0 = rng.normal(size=(M, N))
+    got = _gemm(A, Bm, C0, -1.0, 1.0, 0, tile=40)
+    want = C0 - A @ Bm
+    bound = 1e-12 * (np.abs(A) @ np.abs(Bm) + np.abs(C0))
+    assert np.all(np.abs(got - want) <= bound)
+    got = _gemm(A, Bm, C0, 2.0, 0.0, 0, tile=40)
+    assert np.all(np.abs(got - 2.0 * (A @ Bm)) <= 2 * bound)
+
+
+def test_dgemm_dlds_asymmetric_identity_check():
+    n = 160
+    B = np.arange(n * 96, dtype=float).reshape(n, 96)
+    got = _gemm(np.eye(n), B, np.zeros((n, 96)), 1.0, 0.0, 0, tile=40)
+    assert np.array_equal(got, B)
+
+
 # the short-K direct-to-LDS kernel of the Cholesky / TRSM panel updates (dgemm_dl.h): K % 16 == 0
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (4872, 128, 128), (1000, 1024, 128), (131, 77, 16),
                                    (5, 3, 32), (777, 300, 256), (64, 128, 128)])

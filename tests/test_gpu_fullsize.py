@@ -196,3 +196,39 @@ def test_graph_replay_of_the_factorisation_is_bit_identical_to_eager_launches():
         out[mode] = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["0"] == out["old"] == out["2"]
     assert len(set(out["2"])) == 5 and all(np.isfinite(out["2"]))
+
+
+@pytest.mark.parametrize("n,m", [(2000, 256), (5000, 1024)])
+def test_whole_mcml_iterations_theta_step_on_the_graph_equals_eager_evaluation(n, m, tmp_path):
+    """BASELINE configs 2 and 3 at full size, two whole mcml_full iterations (sampler -> MCNR -> 40-evaluation theta-step
+    on the replayed graph with the m sample columns appended -> L refresh; src/mcml_full.cpp:83-140): every objective
+    value the last theta-step saw is re-evaluated on the same samples by EAGER launches (GLMMR_MCML_CHOL_GRAPH=0, a
+    fresh process) and must agree to the last bit (mcmldmatrix.h:23-41); the fit stays in a band round the generating
+    values (theta = (0.25, 0.1), sigma = 1, beta = 1)."""
+    import json, os, subprocess, sys
+    from glmmrmcml_amd import api
+    d = synth.geospatial(n, seed=20240601)
+    with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"]) as ctx:
+        ctx.theta_log(enable=True)
+        r = ctx.mcml_full(d["start"], mcnr=True, m=m, maxiter=2, warmup=100, tol=0.0, lambda_=5.0, maxsteps=10,
+                          target_accept=0.9, seed=20240601, chains=m, maxfun=40)
+        log = ctx.theta_log(enable=False)
+        u = ctx.get_u()
+    assert r["iters"] == 2 and u.shape == (n, m) and np.all(np.isfinite(u))
+    assert log.shape == (80, 3)                          # 40 evaluations per theta-step
+    last = log[40:]
+    assert 0.1 < r["theta"][0] < 0.6 and 0.03 < r["theta"][1] < 0.3 and 0.7 < r["sigma"] < 1.3 and 0.0 < r["beta"][0] < 2.0
+    assert np.all(np.isfinite(last)) and last[:, 2].max() >= log[:40, 2].max() - 50.0
+    np.save(tmp_path / "u.npy", u); np.save(tmp_path / "th.npy", last[:, :2])
+    code = ("import json, numpy as np\n"
+            "from glmmrmcml_amd import api, synth\n"
+            "d = synth.geospatial(%d, seed=20240601)\n"
+            "ctx = api.Context(d['cov'], d['data'], d['eff_range'])\n"
+            "ctx.set_u(np.load(r'%s'))\n"
+            "print(json.dumps([ctx.mvn_ll(t) for t in np.load(r'%s')]))\n" % (n, tmp_path / "u.npy", tmp_path / "th.npy"))
+    env = dict(os.environ, GLMMR_MCML_CHOL_GRAPH="0")
+    rr = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900,
+                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert rr.returncode == 0, rr.stderr[-2000:]
+    eager = np.array(json.loads(rr.stdout.strip().splitlines()[-1]))
+    assert np.array_equal(eager, last[:, 2]), np.abs(eager - last[:, 2]).max()

@@ -144,7 +144,8 @@ def test_many_chains_recover_gaussian_posterior(orc):
 
 def test_sparse_and_dense_zl_operators_agree(monkeypatch):
     """configs 1/4/5: the ELL/CSR ZL operator (as the product ZL and as the two factors Z, L applied in turn,
-    hmc_cm.h) and the dense MFMA GEMMs are the same sampler"""
+    hmc_cm.h) and the dense n x Q products on the FP64 MFMA kernels (20 chains: more than the streamed few-column
+    kernel takes; asserted) are the same sampler"""
     from glmmrmcml_amd import api
     for gen, kw in ((synth.stepped_wedge, dict(ncl=9, nt=6, nind=12)), (synth.longitudinal, dict(nsubj=50, nvisit=4)),
                     (synth.stepped_wedge, dict(ncl=7, nt=5, nind=40)),       # long rows of ZL' (config 4's regime)
@@ -155,8 +156,10 @@ def test_sparse_and_dense_zl_operators_agree(monkeypatch):
             monkeypatch.setenv("GLMMR_MCML_ZL", mode)
             with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"]) as ctx:
                 ctx.update_L(d["theta"])
-                diag, flags, probs = ctx.hmc_sample(d["beta"], 1.0, 15, 24, 0.4, 8, 0.9, seed=77, chains=12,
+                diag, flags, probs = ctx.hmc_sample(d["beta"], 1.0, 15, 40, 0.4, 8, 0.9, seed=77, chains=20,
                                                     want_trace=True)
+                kinds = set(ctx.last_kernels())
+                assert kinds == {"sparse"} if mode != "dense" else kinds <= {"band", "dlds", "reg"}, (mode, kinds)
                 V = np.random.default_rng(5).normal(size=(d["Q"], 3)) * 0.5
                 lp, G = ctx.log_prob_grad(d["beta"], 1.0, V)
                 out[mode] = (ctx.get_u(), flags.copy(), probs.copy(), lp, G)
@@ -167,3 +170,28 @@ def test_sparse_and_dense_zl_operators_agree(monkeypatch):
             assert np.abs(out["product"][0] - out[mode][0]).max() < 1e-8, mode
             assert np.abs(out["product"][3] - out[mode][3]).max() < 1e-11 * np.abs(out["product"][3]).max(), mode
             assert np.abs(out["product"][4] - out[mode][4]).max() < 1e-11 * max(1.0, np.abs(out["product"][4]).max()), mode
+
+
+def test_dense_z_sampler_runs_the_direct_to_lds_kernel(orc):
+    """a dense, non-identity Z (Householder reflector, bench.py --dense-z): ZL has no structural zeros, more than 16
+    chains -> both products run dgemm_dlds_asm_kernel (asserted), chain by chain against the oracle"""
+    from glmmrmcml_amd import api
+    for n, Cn in ((200, 32), (330, 40)):
+        d = synth.geospatial(n, seed=33)
+        v = np.random.default_rng(n).standard_normal(n); v /= np.linalg.norm(v)
+        d["Z"] = np.asfortranarray(np.eye(n) - 2.0 * np.outer(v, v))
+        ctx, ZL, xb, fl, Lo = _setup(orc, d, api)
+        warm, lam, ms, ta, seed, it = 12, 0.4, 6, 0.9, 99, 1
+        diag, flags, probs = ctx.hmc_sample(d["beta"], d["sigma"], warm, Cn, lam, ms, ta, seed, chains=Cn, iter_idx=it,
+                                            adapt=10, want_trace=True)
+        assert ctx.last_kernels() == ("dlds", "dlds") and ctx.profile(enable=False)["operator"] == "dense"
+        u = ctx.get_u()
+        assert u.shape == (n, Cn)
+        for c in range(Cn):
+            so, fo, po, dg = orc.hmc_chain(xb, ZL, d["y"], d["sigma"], fl, warm, 1, lam, ms, ta, seed, chain_id=c,
+                                           iter_idx=it, adapt=10)
+            assert np.array_equal(flags[c], fo), (n, c)
+            assert np.abs(probs[c] - po).max() < 1e-9
+            uo = Lo @ so[:, 1:]
+            assert np.abs(u[:, c:c + 1] - uo).max() < 1e-8 * max(1.0, np.abs(uo).max())
+        ctx.close()

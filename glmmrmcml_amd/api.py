@@ -187,6 +187,13 @@ class Context:
         _lib.check(_lib.lib().glmmr_mcml_ctx_mvn_ll(self._h, _p(theta), C.byref(out)))
         return out.value
 
+    def mvn_ll_batch(self, thetas):
+        """mvn_ll at several thetas (rows of `thetas`) evaluated side by side on the device"""
+        th = np.ascontiguousarray(np.atleast_2d(np.asarray(thetas, dtype=np.float64)))     # row j = candidate j = column-major R x k
+        out = np.zeros(th.shape[0])
+        _lib.check(_lib.lib().glmmr_mcml_ctx_mvn_ll_batch(self._h, _p(th), th.shape[0], _p(out)))
+        return out
+
     def gen_D(self, theta, chol=False):
         theta = _f(theta).ravel()
         D = np.zeros((self.Q, self.Q), order="F")

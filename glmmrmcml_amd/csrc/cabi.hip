@@ -212,6 +212,22 @@ extern "C" int glmmr_mcml_ctx_mvn_ll(glmmr_mcml_ctx* h, const double* theta, dou
     return MCML_OK;
 }
 
+extern "C" int glmmr_mcml_ctx_mvn_ll_batch(glmmr_mcml_ctx* h, const double* thetas, int k, double* out)
+{
+    MCML_REQUIRE(h && thetas && out && k >= 1 && k <= 64, "mvn_ll_batch: bad argument");
+    Ctx& c = h->c;
+    MCML_HIP(hipSetDevice(c.device));
+    MCML_REQUIRE(c.mcols > 0 && c.U.d(), "mvn_ll: no samples set");
+    std::vector<double> tot(k + 1, 0.0);
+    std::vector<int> rcs(k, 0);
+    MCML_TRY(mvn_loglik_batch(c, thetas, k, c.U.d(), c.U.ld, c.mcols, tot.data(), rcs.data()));
+    for (int j = 0; j < k; ++j) if (rcs[j] == MCML_ENOTPD) tot[j] = NAN;          // a sum with NaN stays NaN on every rank
+    tot[k] = (double)c.mcols;
+    MCML_TRY(allreduce_host(c, tot.data(), k + 1));
+    for (int j = 0; j < k; ++j) out[j] = tot[j] / tot[k];
+    return MCML_OK;
+}
+
 extern "C" int glmmr_mcml_ctx_gen_D(glmmr_mcml_ctx* h, const double* theta, int chol, double* out, int ldo)
 {
     MCML_REQUIRE(h && theta && out, "gen_D: null argument");
@@ -299,7 +315,7 @@ extern "C" int glmmr_mcml_ctx_set_L(glmmr_mcml_ctx* h, const double* L, int ldl)
     c.have_L = true;
     // a caller-supplied L need not have the block pattern the sparse ZL operator assumes (entries outside the
     // covariance blocks would be dropped): the dense products take whatever L holds
-    c.no_sparse_zl = true;
+    c.l_foreign = true;
     MCML_TRY(model_update_L(c));
     return c.sync();
 }

@@ -109,6 +109,64 @@ struct KernelProf {
     ~KernelProf() { for (auto e : ev) (void)hipEventDestroy(e); }
 };
 
+// the factorisation's launch sequence as a hipGraph (mvn.hip potrf_graphed): the theta-step evaluates the same
+// (matrix, shape) dozens of times per MCML iteration; key = what the captured kernels' arguments depend on
+struct CholGraph {
+    hipGraphExec_t exec = nullptr;
+    const double* A = nullptr; const double* linv = nullptr; int lda = 0, n = 0, extra = 0, seen = 0;
+    long long used = 0;                 // launch counter value at the last use (the least recently used entry is replaced)
+};
+// a few graphs side by side: a model with two or more large covariance blocks of different size evaluates them in turn,
+// and a one-entry cache would re-capture (i.e. run eagerly) every time
+struct CholGraphCache {
+    static constexpr int CAP = 4;
+    std::vector<CholGraph> g;
+    long long tick = 0;
+    void clear() { for (CholGraph& e : g) if (e.exec) (void)hipGraphExecDestroy(e.exec); g.clear(); }
+    ~CholGraphCache() { clear(); }
+    CholGraphCache() = default;
+    CholGraphCache(const CholGraphCache&) = delete;
+    CholGraphCache& operator=(const CholGraphCache&) = delete;
+    CholGraphCache(CholGraphCache&& o) noexcept : g(std::move(o.g)), tick(o.tick) { o.g.clear(); }
+    CholGraphCache& operator=(CholGraphCache&& o) noexcept { if (this != &o) { clear(); g = std::move(o.g); tick = o.tick; o.g.clear(); } return *this; }
+    CholGraph& find(const double* A, const double* linv, int lda, int n, int extra) {
+        ++tick;
+        for (CholGraph& e : g)
+            if (e.A == A && e.linv == linv && e.lda == lda && e.n == n && e.extra == extra) { e.used = tick; return e; }
+        if ((int)g.size() < CAP) g.push_back(CholGraph());
+        else {
+            size_t old = 0;
+            for (size_t i = 1; i < g.size(); ++i) if (g[i].used < g[old].used) old = i;
+            if (g[old].exec) (void)hipGraphExecDestroy(g[old].exec);
+            g[old] = CholGraph();
+            std::swap(g[old], g.back());
+        }
+        CholGraph& e = g.back();
+        e.A = A; e.linv = linv; e.lda = lda; e.n = n; e.extra = extra; e.seen = 0; e.used = tick;
+        return e;
+    }
+};
+
+// An independent evaluation slot of the MVN log-likelihood: its own stream, workspaces, look-ahead streams / events
+// and captured graph.  One evaluation of a large dense block is a latency chain (0.24 of the FP64 MFMA peak at
+// Q = 5000): several candidate thetas evaluated side by side, one per lane, fill the chip (mvn.hip mvn_loglik_batch).
+// A lane is swapped INTO the context's own fields while its work is enqueued, so the kernels' host code is the same.
+struct MvnLane {
+    hipStream_t stream = nullptr, aux = nullptr, aux_lo = nullptr;
+    hipEvent_t ev_col = nullptr, ev_leaf = nullptr, ev_ps = nullptr, ev_b = nullptr;
+    DevMat Dwork, Uwork;
+    DevBuf linv, partials, scalars, scratch;
+    CholGraphCache chol_graphs;
+    std::vector<hipEvent_t> ev_ring;   // one event per dependency edge of the captured schedule (mvn.hip)
+    double* host = nullptr;            // pinned: [sum, error flag]
+    ~MvnLane() {
+        for (hipEvent_t e : ev_ring) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ev_col, ev_leaf, ev_ps, ev_b}) if (e) (void)hipEventDestroy(e);
+        for (hipStream_t st : {stream, aux, aux_lo}) if (st) (void)hipStreamDestroy(st);
+        if (host) (void)hipHostFree(host);
+    }
+};
+
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -121,6 +179,8 @@ struct Ctx {
     std::vector<int> h_zidx; std::vector<double> h_zval;   // host copy of the same
     SparseZL sp;
     bool no_sparse_zl = false;  // the Laplace path works on the dense ZL / ZLT
+    bool l_foreign = false;     // L came from the caller (set_L), not from theta: it need not have the block pattern the
+                                // sparse ZL operator assumes; cleared as soon as L is regenerated from theta (mvn_gen_L)
     CovSpec cov;
     DevMat Z, X;                // n x Q, n x P
     DevBuf y;                   // n
@@ -185,15 +245,15 @@ struct Ctx {
     hipStream_t aux = nullptr;      // high priority: the leaf of the eager fork-join
     hipStream_t aux_lo = nullptr;   // lowest priority: the bulk chain of the captured schedule
     hipEvent_t ev_col = nullptr, ev_leaf = nullptr, ev_ps = nullptr, ev_b = nullptr;
-    // the factorisation's launch sequence as a hipGraph (mvn.hip potrf_graphed): the theta-step evaluates the same
-    // (matrix, shape) dozens of times per MCML iteration; key = what the captured kernels' arguments depend on
-    struct CholGraph {
-        hipGraphExec_t exec = nullptr;
-        const double* A = nullptr; const double* linv = nullptr; int lda = 0, n = 0, extra = 0, seen = 0;
-    } chol_graph;
+    CholGraphCache chol_graphs;
+    std::vector<hipEvent_t> ev_ring;                 // one event per dependency edge of the captured schedule (mvn.hip)
+    std::vector<std::unique_ptr<MvnLane>> lanes;     // mvn_loglik_batch
+    hipEvent_t ev_lanes = nullptr;                   // the lanes start behind everything already on `stream`
     ~Ctx() {
+        lanes.clear();
+        for (hipEvent_t e : ev_ring) if (e) (void)hipEventDestroy(e);
+        if (ev_lanes) (void)hipEventDestroy(ev_lanes);
         comm_release_hook();
-        if (chol_graph.exec) (void)hipGraphExecDestroy(chol_graph.exec);
         if (ev_col) (void)hipEventDestroy(ev_col);
         if (ev_leaf) (void)hipEventDestroy(ev_leaf);
         if (ev_ps) (void)hipEventDestroy(ev_ps);
@@ -220,6 +280,8 @@ int mvn_setup(Ctx& c);
 int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out);
 // the same over the m columns of any resident sample matrix (Q x m, leading dimension ldu)
 int mvn_loglik_sum_on(Ctx& c, const double* theta, const double* U, int ldu, int m, double* sum_out);
+// k candidate thetas (npar x k, column-major) side by side, one per lane: sums[j], rcs[j] = MCML_OK | MCML_ENOTPD
+int mvn_loglik_batch(Ctx& c, const double* thetas, int k, const double* U, int ldu, int m, double* sums, int* rcs);
 // L = genD(0, chol=true, upper=false) (mcml_full.cpp:68): block-diagonal lower factor
 int mvn_gen_L(Ctx& c, const double* theta, bool chol);
 int potrf_lower(Ctx& c, double* A, int n, int lda);                          // in place

@@ -96,20 +96,28 @@ struct McmlOptim {
         const int wr = comm_world(c), mall = c.mcols * wr;
         batch_objective_fn fb = [&](const std::vector<std::vector<double>>& Zs, std::vector<double>* F) -> int {
             const int nc = (int)Zs.size();
-            std::vector<double> vals(nc, 0.0), th(R);
+            std::vector<double> vals(nc, 0.0);
             const bool emu = c.world <= 1 && !c.comm && c.emu_world > 1;
             int first_rc = MCML_OK;
-            for (int j = 0; j < nc; ++j) {
-                const bool mine = (j % wr) == c.rank;
-                if (!mine && !(emu && c.emu_mode == 1)) continue;
-                for (int i = 0; i < R; ++i) th[i] = std::exp(Zs[j][i]);
-                double sum = 0;
-                const int rc = mvn_loglik_sum_on(c, th.data(), c.Uall.d(), c.Uall.ld, mall, &sum);
-                if (rc == MCML_ENOTPD) vals[j] = HUGE_VAL;               // as eval_mvn: infinitely bad, not an error
-                else if (rc != MCML_OK) { vals[j] = NAN; if (first_rc == MCML_OK) first_rc = rc; }
-                else vals[j] = -1 * (sum / mall);
-                if (mine) ++c.theta_evals_own;
-                if (c.theta_log_on && rc == MCML_OK) { c.theta_log.insert(c.theta_log.end(), th.begin(), th.end()); c.theta_log.push_back(sum / mall); }
+            // this rank's candidates of the round, side by side (one evaluation lane each: mvn.hip mvn_loglik_batch)
+            std::vector<int> own;
+            for (int j = 0; j < nc; ++j)
+                if ((j % wr) == c.rank || (emu && c.emu_mode == 1)) own.push_back(j);
+            if (!own.empty()) {
+                std::vector<double> ths((size_t)R * own.size()), sums(own.size(), 0.0);
+                std::vector<int> rcs(own.size(), 0);
+                for (size_t q = 0; q < own.size(); ++q)
+                    for (int i = 0; i < R; ++i) ths[q * R + i] = std::exp(Zs[own[q]][i]);
+                const int brc = mvn_loglik_batch(c, ths.data(), (int)own.size(), c.Uall.d(), c.Uall.ld, mall, sums.data(), rcs.data());
+                for (size_t q = 0; q < own.size(); ++q) {
+                    const int j = own[q];
+                    const int rc = (rcs[q] == MCML_OK && brc != MCML_OK) ? brc : rcs[q];
+                    if (rc == MCML_ENOTPD) vals[j] = HUGE_VAL;               // as eval_mvn: infinitely bad, not an error
+                    else if (rc != MCML_OK) { vals[j] = NAN; if (first_rc == MCML_OK) first_rc = rc; }
+                    else vals[j] = -1 * (sums[q] / mall);
+                    if ((j % wr) == c.rank) ++c.theta_evals_own;
+                    if (c.theta_log_on && rc == MCML_OK) { c.theta_log.insert(c.theta_log.end(), ths.begin() + q * R, ths.begin() + (q + 1) * R); c.theta_log.push_back(sums[q] / mall); }
+                }
             }
             c.theta_rounds += 1; c.theta_evals_all += nc;
             if (!emu) MCML_TRY(allreduce_host(c, vals.data(), nc));      // every slot is zero on all ranks but its owner

@@ -249,7 +249,7 @@ int model_update_L(Ctx& c)
 {
     MCML_REQUIRE(c.n > 0 && c.have_L, "update_L: no model / L");
     if (!c.sp.built) MCML_TRY(sparse_zl_setup(c));
-    if (c.sp.possible && !c.no_sparse_zl && c.L.ld == pad_ld(c.Q)) {
+    if (c.sp.possible && !c.no_sparse_zl && !c.l_foreign && c.L.ld == pad_ld(c.Q)) {
         const long tot = (long)c.n * c.sp.W;
         hipLaunchKernelGGL(k_ell_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c.stream,
                            c.sp.ell_src.as<int>(), c.sp.ell_z.d(), c.L.d(), tot, c.sp.ell_val.d());
@@ -290,7 +290,10 @@ int model_update_L(Ctx& c)
             std::vector<int> h(2 * (size_t)nb);
             MCML_HIP(hipMemcpyAsync(h.data(), c.kr_scratch.p, sizeof(int) * h.size(), hipMemcpyDeviceToHost, c.stream));
             MCML_HIP(hipStreamSynchronize(c.stream));
-            plan.reset(M, K, h);               // the per-chain-count decompositions are rebuilt on first use
+            // the K-tile ranges of a triangular ZL do not change from one MCML iteration to the next: keep the device
+            // plans (work lists, partial-tile buffers) unless they did
+            if (!(plan.M == M && plan.K == K && plan.kr == h))
+                plan.reset(M, K, h);           // the per-chain-count decompositions are rebuilt on first use
             const long dense = (long)nb * ((K + BD_BK - 1) / BD_BK);
             use = (env && !strcmp(env, "band")) || plan.tiles * 5 <= dense * 4;
             ntiles = plan.tiles;

@@ -669,8 +669,8 @@ static int lookahead_setup(Ctx& c)
 // whole trailing update except that block, one launch, lower tiles only, balanced over the XCDs.  The leaf
 // (ONE workgroup that needs a whole CU's LDS) becomes ready together with the bulk and is dispatched first, so
 // it never waits for a CU to drain.  The main stream joins the leaf before step t+1.  Period: two small GEMMs
-// + max(bulk, leaf).  (A freer two-queue schedule with the bulk on a CU-masked stream measured ~10 % faster
-// but hung intermittently in cross-stream waits; this fork-join is the round-1 pattern, which never did.)
+// + max(bulk, leaf).  (A freer two-queue schedule measured ~10 % faster live but
+// hung intermittently; it exists as a captured graph only -- see "the hang" above potrf_la2_capture.)
 //   GLMMR_MCML_CHOL=rec : the recursive variant;  =nola : everything on one stream
 static int potrf_blocked(Ctx& c, double* A, int lda, int n, int extra)
 {
@@ -730,8 +730,7 @@ static int potrf_blocked(Ctx& c, double* A, int lda, int n, int extra)
     return MCML_OK;
 }
 
-// The dependency structure the GRAPH is captured with (never launched eagerly: with cross waits in both directions
-// between two live streams the process deadlocked intermittently, see above; a captured graph has no stream waits).
+// The dependency structure the GRAPH is captured with (never launched eagerly, see "the hang" below).
 // Two chains that only meet through events:
 //   critical (capture stream):  P_small(t)  the 128 x 128 panel block under the diagonal block, X <- X inv(L_t)'
 //                               U_small(t)  D_{t+1} -= X X'
@@ -740,10 +739,35 @@ static int potrf_blocked(Ctx& c, double* A, int lda, int n, int extra)
 //                               b(t)  column blocks t+1 AND t+2, rows below block t+1, -= panel t   (needs P_small(t))
 //                               c(t)  column blocks t+3.., lower tiles only, -= panel t
 // P_small(t+1) / U_small(t+1) touch block (t+2, t+1) and D_{t+2}: both were brought up to date by b(t), so the
-// critical chain waits for b(t) only -- never for the big update c(t) -- and its three kernels sit back to back on one
-// queue; the bulk chain is self-contained (its two waits are satisfied early because the critical chain runs ahead).
+// critical chain waits for b(t) and never for the big update c(t) OF THE SAME STEP.  It is not independent of the big
+// updates: b(t) sits behind c(t-1) on the bulk queue (and must: column block t+2 was last written by c(t-1)), so the
+// critical chain has one step of slack against the bulk chain, which is what the early, throughput-bound steps use up;
+// in the late steps the bulk chain runs ahead and the three critical kernels sit back to back on one queue.
 // Every tile still receives its updates in panel order from kernels that accumulate k = 0..127 in order: the factor
 // is bit-identical to potrf_blocked's.
+//
+// The hang (round 2: this structure as two LIVE streams, cross waits both ways, hung the process -- not the GPU -- on
+// three of ~20 boxes; no log of it was kept).  What the code says: the dependency structure is acyclic if every
+// hipStreamWaitEvent binds to the event's record AT THE TIME OF THE CALL, which is what HIP documents (CUDA's
+// semantics) and what a capture does by construction -- the same structure has replayed > 27 000 times as a graph.
+// The live version re-recorded the SAME four events every step while the other stream could still hold a pending
+// wait on the previous record.  If the runtime ever resolves such a wait against the event's LATEST record instead,
+// the bulk stream's wait for leaf(t+1) can land on leaf(t+2), which waits (through P_small(t+2)) for b(t+1) on the
+// bulk stream behind that very wait: a cycle, and a host thread blocked in the next enqueue on a full queue -- the
+// observed symptom.  That reading cannot be proved without the runtime's source; what is done instead is to remove
+// the question: every dependency edge below has ITS OWN event (a ring, never re-recorded within a capture), so no wait
+// can be bound to anything but the one record it was written for, and live launches keep the fork-join of
+// potrf_blocked, whose waits always follow the record they mean on the same host thread with no later record pending.
+// If the two-chain schedule is ever wanted live again, it must use the same ring.
+static hipEvent_t ring_event(Ctx& c, size_t idx)
+{
+    while (c.ev_ring.size() <= idx) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        c.ev_ring.push_back(e);
+    }
+    return c.ev_ring[idx];
+}
 static int potrf_la2_capture(Ctx& c, double* A, int lda, int n, int extra)
 {
     int* errflag = c.scalars.as<int>() + 32;
@@ -762,10 +786,13 @@ static int potrf_la2_capture(Ctx& c, double* A, int lda, int n, int extra)
         return launch_gemm<true>(st, M, N, K, Ap, lda, Bp, ldb, epi, lower, inplace ? inplace : -1);
     };
     const int nsteps = (n + CHOL_NB - 1) / CHOL_NB;
+    // one event per dependency edge: 3 per step (leaf, P_small, b) + the first leaf + the join
+    auto EV = [&](int step, int kind) -> hipEvent_t { return ring_event(c, (size_t)3 * (step + 1) + kind); };
+    MCML_REQUIRE(ring_event(c, (size_t)3 * (nsteps + 2)) != nullptr, "potrf: could not create the capture's events");
     MCML_TRY(leaf(0, n < CHOL_NB ? n : CHOL_NB));
-    MCML_HIP(hipEventRecord(c.ev_leaf, sC));
-    MCML_HIP(hipStreamWaitEvent(sB, c.ev_leaf, 0));                  // the side stream joins the capture; a(0) needs leaf(0)
-    bool have_b = false;
+    MCML_HIP(hipEventRecord(EV(-1, 0), sC));
+    MCML_HIP(hipStreamWaitEvent(sB, EV(-1, 0), 0));                  // the side stream joins the capture; a(0) needs leaf(0)
+    hipEvent_t last_b = nullptr;
     for (int t = 0; t < nsteps; ++t) {
         const int k = t * CHOL_NB;
         const int nb = (n - k < CHOL_NB) ? n - k : CHOL_NB;
@@ -779,38 +806,38 @@ static int potrf_la2_capture(Ctx& c, double* A, int lda, int n, int extra)
         const int w = nb2 + nb3;                                      // columns b(t) covers
         // ---- critical chain
         if (nb2 > 0) {
-            if (have_b) MCML_HIP(hipStreamWaitEvent(sC, c.ev_b, 0));  // b(t-1)
+            if (last_b) MCML_HIP(hipStreamWaitEvent(sC, last_b, 0));  // b(t-1)
             MCML_TRY(gemm_nt(sC, nb2, nb, nb, A21, Linv, CHOL_NB, A21, 1.0, 0.0, false, 7, 1));
             double* T = A11 + nb + (size_t)nb * lda;
             MCML_TRY(gemm_nt(sC, nb2, nb2, nb, A21, A21, lda, T, -1.0, 1.0, false, 8, 0));
-            MCML_HIP(hipEventRecord(c.ev_ps, sC));
+            MCML_HIP(hipEventRecord(EV(t, 1), sC));
             MCML_TRY(leaf(k + nb, nb2));
-            MCML_HIP(hipEventRecord(c.ev_leaf, sC));
+            MCML_HIP(hipEventRecord(EV(t, 0), sC));
         }
         // ---- bulk chain
         const int Rb = R - nb2;
         if (Rb > 0) {
             MCML_TRY(gemm_nt(sB, Rb, nb, nb, A21 + nb2, Linv, CHOL_NB, A21 + nb2, 1.0, 0.0, false, 0, 1));
             if (nb2 > 0) {
-                MCML_HIP(hipStreamWaitEvent(sB, c.ev_ps, 0));
+                MCML_HIP(hipStreamWaitEvent(sB, EV(t, 1), 0));
                 double* Cb = A11 + nb + nb2 + (size_t)nb * lda;       // rows below block t+1, columns of blocks t+1, t+2
                 MCML_TRY(gemm_nt(sB, Rb, w, nb, A21 + nb2, A21, lda, Cb, -1.0, 1.0, false, 0, 0));
-                MCML_HIP(hipEventRecord(c.ev_b, sB));
-                have_b = true;
+                MCML_HIP(hipEventRecord(EV(t, 2), sB));
+                last_b = EV(t, 2);
                 if (rem - w > 0) {
                     double* Cc = A11 + nb + w + (size_t)(nb + w) * lda;
                     MCML_TRY(gemm_nt(sB, R - w, rem - w, nb, A21 + w, A21 + w, lda, Cc, -1.0, 1.0, true, 0, 0));
                 }
             }
         } else if (nb2 > 0) {
-            MCML_HIP(hipStreamWaitEvent(sB, c.ev_ps, 0));             // keep the side stream a descendant of every node
-            MCML_HIP(hipEventRecord(c.ev_b, sB));
-            have_b = true;
+            MCML_HIP(hipStreamWaitEvent(sB, EV(t, 1), 0));            // keep the side stream a descendant of every node
+            MCML_HIP(hipEventRecord(EV(t, 2), sB));
+            last_b = EV(t, 2);
         }
-        if (nb2 > 0) MCML_HIP(hipStreamWaitEvent(sB, c.ev_leaf, 0));  // a(t+1) needs leaf(t+1)
+        if (nb2 > 0) MCML_HIP(hipStreamWaitEvent(sB, EV(t, 0), 0));   // a(t+1) needs leaf(t+1)
     }
-    MCML_HIP(hipEventRecord(c.ev_b, sB));                             // join
-    MCML_HIP(hipStreamWaitEvent(sC, c.ev_b, 0));
+    MCML_HIP(hipEventRecord(EV(nsteps, 0), sB));                      // join
+    MCML_HIP(hipStreamWaitEvent(sC, EV(nsteps, 0), 0));
     return MCML_OK;
 }
 
@@ -833,13 +860,8 @@ static bool chol_graph_on() { return chol_graph_kind() != 0; }
 static int potrf_graphed(Ctx& c, double* A, int lda, int n, int extra)
 {
     if (!chol_graph_on() || !(chol_mode() == 1 && n > 2 * CHOL_NB)) return potrf_blocked(c, A, lda, n, extra);
-    Ctx::CholGraph& g = c.chol_graph;
-    const bool same = g.A == A && g.linv == c.linv.d() && g.lda == lda && g.n == n && g.extra == extra;
-    if (same && g.exec) { MCML_HIP(hipGraphLaunch(g.exec, c.stream)); return MCML_OK; }
-    if (!same) {
-        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-        g.A = A; g.linv = c.linv.d(); g.lda = lda; g.n = n; g.extra = extra; g.seen = 0;
-    }
+    CholGraph& g = c.chol_graphs.find(A, c.linv.d(), lda, n, extra);
+    if (g.exec) { MCML_HIP(hipGraphLaunch(g.exec, c.stream)); return MCML_OK; }
     if (g.seen++ <= 0) return potrf_blocked(c, A, lda, n, extra);          // eager first: attributes, allocations
     MCML_TRY(lookahead_setup(c));
     if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
@@ -1002,7 +1024,76 @@ int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out)
     return mvn_loglik_sum_on(c, theta, c.U.d(), c.U.ld, c.mcols, sum_out);
 }
 
+static int mvn_loglik_enqueue(Ctx& c, const double* theta, const double* Us, int ldu, int m);
+
 int mvn_loglik_sum_on(Ctx& c, const double* theta, const double* Us, int ldu, int m, double* sum_out)
+{
+    MCML_TRY(mvn_loglik_enqueue(c, theta, Us, ldu, m));
+    MCML_HIP(hipMemcpyAsync(sum_out, c.scalars.d(), sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    MCML_TRY(check_errflag(c, "mvn_ll"));
+    return MCML_OK;
+}
+
+static void lane_swap(Ctx& c, MvnLane& l)
+{
+    std::swap(c.stream, l.stream); std::swap(c.aux, l.aux); std::swap(c.aux_lo, l.aux_lo);
+    std::swap(c.ev_col, l.ev_col); std::swap(c.ev_leaf, l.ev_leaf); std::swap(c.ev_ps, l.ev_ps); std::swap(c.ev_b, l.ev_b);
+    std::swap(c.Dwork, l.Dwork); std::swap(c.Uwork, l.Uwork);
+    std::swap(c.linv, l.linv); std::swap(c.partials, l.partials); std::swap(c.scalars, l.scalars); std::swap(c.scratch, l.scratch);
+    std::swap(c.chol_graphs, l.chol_graphs); std::swap(c.ev_ring, l.ev_ring);
+}
+
+// Candidate j runs on lane j: the same launches as mvn_loglik_sum_on, on the lane's stream and workspaces, with no
+// host synchronisation until every candidate has been enqueued.
+int mvn_loglik_batch(Ctx& c, const double* thetas, int k, const double* Us, int ldu, int m, double* sums, int* rcs)
+{
+    MCML_REQUIRE(k >= 1 && thetas && sums && rcs, "mvn_ll batch: bad arguments");
+    const int R = c.cov.npar;
+    if (k == 1) {                         // nothing to run beside it: the context's own stream and workspace
+        rcs[0] = mvn_loglik_sum_on(c, thetas, Us, ldu, m, sums);
+        if (rcs[0] == MCML_ENOTPD) return MCML_OK;
+        return rcs[0];
+    }
+    while ((int)c.lanes.size() < k) {
+        std::unique_ptr<MvnLane> l(new MvnLane());
+        MCML_HIP(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+        MCML_TRY(l->scalars.ensure(sizeof(double) * 64));
+        MCML_HIP(hipMemsetAsync(l->scalars.p, 0, sizeof(double) * 64, l->stream));
+        MCML_HIP(hipHostMalloc(reinterpret_cast<void**>(&l->host), sizeof(double) * 2, hipHostMallocDefault));
+        MCML_HIP(hipStreamSynchronize(l->stream));
+        c.lanes.push_back(std::move(l));
+    }
+    if (!c.ev_lanes) MCML_HIP(hipEventCreateWithFlags(&c.ev_lanes, hipEventDisableTiming));
+    MCML_HIP(hipEventRecord(c.ev_lanes, c.stream));              // the samples are where the lanes will read them
+    int first_rc = MCML_OK;
+    for (int j = 0; j < k; ++j) {
+        MvnLane& l = *c.lanes[j];
+        MCML_HIP(hipStreamWaitEvent(l.stream, c.ev_lanes, 0));
+        lane_swap(c, l);
+        int rc = mvn_loglik_enqueue(c, thetas + (size_t)j * R, Us, ldu, m);
+        if (rc == MCML_OK) {
+            hipError_t e = hipMemcpyAsync(l.host, c.scalars.d(), sizeof(double), hipMemcpyDeviceToHost, c.stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(l.host + 1, c.scalars.as<int>() + 32, sizeof(int), hipMemcpyDeviceToHost, c.stream);
+            if (e == hipSuccess) e = hipMemsetAsync(c.scalars.as<int>() + 32, 0, sizeof(int), c.stream);
+            if (e != hipSuccess) { set_error("mvn_ll batch: %s", hipGetErrorString(e)); rc = MCML_EHIP; }
+        }
+        lane_swap(c, l);
+        rcs[j] = rc;
+        if (rc != MCML_OK && first_rc == MCML_OK) first_rc = rc;
+    }
+    for (int j = 0; j < k; ++j) {
+        MvnLane& l = *c.lanes[j];
+        const hipError_t e = hipStreamSynchronize(l.stream);
+        if (e != hipSuccess && first_rc == MCML_OK) { set_error("mvn_ll batch: %s", hipGetErrorString(e)); first_rc = MCML_EHIP; }
+        if (rcs[j] != MCML_OK) continue;
+        sums[j] = l.host[0];
+        int flag; memcpy(&flag, l.host + 1, sizeof(int));
+        if (flag) rcs[j] = MCML_ENOTPD;
+    }
+    return first_rc;
+}
+
+static int mvn_loglik_enqueue(Ctx& c, const double* theta, const double* Us, int ldu, int m)
 {
     MCML_REQUIRE(m > 0 && Us, "mvn_ll: no samples set");
     ThetaArg th;
@@ -1098,8 +1189,6 @@ int mvn_loglik_sum_on(Ctx& c, const double* theta, const double* Us, int ldu, in
             MCML_HIP(hipGetLastError());
         }
     }
-    MCML_HIP(hipMemcpyAsync(sum_out, scal, sizeof(double), hipMemcpyDeviceToHost, c.stream));
-    MCML_TRY(check_errflag(c, "mvn_ll"));
     return MCML_OK;
 }
 
@@ -1161,6 +1250,7 @@ int mvn_gen_L(Ctx& c, const double* theta, bool chol)
     }
     MCML_HIP(hipGetLastError());
     MCML_TRY(check_errflag(c, "genD"));
+    if (chol) c.l_foreign = false;
     c.have_L = chol;
     return MCML_OK;
 }

@@ -70,3 +70,51 @@ def test_la_through_the_caller():
     h = m.MCML(d["y"], verbose=False, max_iter=5, seed=3, chains=16, options=dict(maxfun=60))
     se = np.asarray(f["coefficients"]["SE"][:P])
     assert np.all(np.abs(np.asarray(f["theta"][:P]) - np.asarray(h["theta"][:P])) < 2.0 * se)
+
+
+@pytest.mark.parametrize("family", ["poisson", "gaussian"])
+def test_post_processing_against_the_oracle(family, orc):
+    """What ModelMCML$MCML does AFTER the fit (R6ModelExtMCML.R:429-585) checked against a second implementation: the
+    standard errors it reports = sqrt(diag(inverse)) of the ORACLE's finite-difference Hessian (oracle/drivers.mcml_hess:
+    optimhess over the C oracle's objective, src/mcml_optim.cpp:263-285) on the same samples and estimates, the cAIC =
+    the oracle's aic_mcml (mcml_optim.cpp:356-392), the random-effect rows = mean / sd of the samples, and the R-squared
+    pieces recomputed in numpy from the oracle's weights (orc_dhdmu) -- R6ModelExtMCML.R:555-569."""
+    from oracle import drivers as od
+    if family == "gaussian":
+        d = synth.geospatial(60, seed=12)
+        m = ModelMCML(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["family"], d["link"], d["beta"], d["theta"],
+                      var_par=d["sigma"], x_names=["int"], cov_names=["fexp"])
+    else:
+        d = synth.cluster_rct(ncl=8, nt=3, nind=8, seed=5, family=family)
+        m = ModelMCML(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["family"], d["link"], d["beta"], d["theta"],
+                      x_names=["int"] + ["t%d" % i for i in range(1, d["P"])], cov_names=["gr(cl)", "gr(cl,t)"])
+    m.mcmc_options.update(warmup=60, samps=48, lambda_=0.5, maxsteps=10)
+    fit = m.MCML(d["y"], verbose=False, max_iter=3, seed=21, chains=8, se_method="lik", options=dict(fd_tol=1e-4))
+    P, R = d["P"], len(d["theta"])
+    u = np.asfortranarray(fit["re_samps"]); th = fit["theta"]
+    mod = od.Model(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"])
+    # --- SE from the Hessian (:448-477; defect D6 fixed: the inverse of what mcml_hess returns)
+    assert fit["hessian"] is True
+    H = od.mcml_hess(mod, u, th, tol=1e-4)
+    se_orc = np.sqrt(np.diag(np.linalg.inv(H)))[:P + R]
+    se = fit["coefficients"]["SE"][:P + R]
+    assert np.all(np.isfinite(se_orc)) and np.abs(se - se_orc).max() < 2e-3 * np.abs(se_orc).max(), (se, se_orc)
+    # --- cAIC (:542-553)
+    mf = np.r_[th[:P], th[P + R]] if family == "gaussian" else th[:P]
+    want_aic = od.aic_mcml(mod, u, mf, th[P:P + R])
+    assert abs(fit["aic"] - want_aic) < 1e-8 * abs(want_aic)
+    # --- random-effect rows of the coefficient table (:529-540)
+    co = fit["coefficients"]
+    nfix = P + R + (1 if family == "gaussian" else 0)
+    assert np.allclose(co["est"][nfix:], u.mean(axis=1), rtol=0, atol=1e-12)
+    assert np.allclose(co["SE"][nfix:], u.std(axis=1, ddof=1), rtol=0, atol=1e-12)
+    assert np.allclose(co["lower"], co["est"] - 1.959964 * co["SE"], equal_nan=True, rtol=1e-6, atol=1e-9)
+    # --- approximate R-squared (:555-569) from the oracle's dh/dmu
+    xb = d["X"] @ th[:P]
+    w = np.asarray(orc.dhdmu(xb, orc.flink(d["family"], d["link"])), float).ravel()
+    if family == "gaussian":
+        w = th[P + R] * w
+    zd = d["Z"] @ u.mean(axis=1)
+    vx, vz = np.var(xb, ddof=1), np.var(zd, ddof=1)
+    tot = vx + vz + w.mean()
+    assert abs(fit["Rsq"]["cond"] - (vx + vz) / tot) < 1e-10 and abs(fit["Rsq"]["marg"] - vx / tot) < 1e-10

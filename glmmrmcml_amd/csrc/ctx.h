@@ -147,26 +147,6 @@ struct CholGraphCache {
     }
 };
 
-// An independent evaluation slot of the MVN log-likelihood: its own stream, workspaces, look-ahead streams / events
-// and captured graph.  One evaluation of a large dense block is a latency chain (0.24 of the FP64 MFMA peak at
-// Q = 5000): several candidate thetas evaluated side by side, one per lane, fill the chip (mvn.hip mvn_loglik_batch).
-// A lane is swapped INTO the context's own fields while its work is enqueued, so the kernels' host code is the same.
-struct MvnLane {
-    hipStream_t stream = nullptr, aux = nullptr, aux_lo = nullptr;
-    hipEvent_t ev_col = nullptr, ev_leaf = nullptr, ev_ps = nullptr, ev_b = nullptr;
-    DevMat Dwork, Uwork;
-    DevBuf linv, partials, scalars, scratch;
-    CholGraphCache chol_graphs;
-    std::vector<hipEvent_t> ev_ring;   // one event per dependency edge of the captured schedule (mvn.hip)
-    double* host = nullptr;            // pinned: [sum, error flag]
-    ~MvnLane() {
-        for (hipEvent_t e : ev_ring) if (e) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {ev_col, ev_leaf, ev_ps, ev_b}) if (e) (void)hipEventDestroy(e);
-        for (hipStream_t st : {stream, aux, aux_lo}) if (st) (void)hipStreamDestroy(st);
-        if (host) (void)hipHostFree(host);
-    }
-};
-
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -247,12 +227,10 @@ struct Ctx {
     hipEvent_t ev_col = nullptr, ev_leaf = nullptr, ev_ps = nullptr, ev_b = nullptr;
     CholGraphCache chol_graphs;
     std::vector<hipEvent_t> ev_ring;                 // one event per dependency edge of the captured schedule (mvn.hip)
-    std::vector<std::unique_ptr<MvnLane>> lanes;     // mvn_loglik_batch
-    hipEvent_t ev_lanes = nullptr;                   // the lanes start behind everything already on `stream`
+    DevMat Dbatch;                                   // mvn_loglik_batch: the candidates' matrices side by side
+    DevBuf bscal;                                    // ... and their result scalars (4 per candidate)
     ~Ctx() {
-        lanes.clear();
         for (hipEvent_t e : ev_ring) if (e) (void)hipEventDestroy(e);
-        if (ev_lanes) (void)hipEventDestroy(ev_lanes);
         comm_release_hook();
         if (ev_col) (void)hipEventDestroy(ev_col);
         if (ev_leaf) (void)hipEventDestroy(ev_leaf);
@@ -280,7 +258,7 @@ int mvn_setup(Ctx& c);
 int mvn_loglik_sum(Ctx& c, const double* theta, double* sum_out);
 // the same over the m columns of any resident sample matrix (Q x m, leading dimension ldu)
 int mvn_loglik_sum_on(Ctx& c, const double* theta, const double* U, int ldu, int m, double* sum_out);
-// k candidate thetas (npar x k, column-major) side by side, one per lane: sums[j], rcs[j] = MCML_OK | MCML_ENOTPD
+// k candidate thetas (npar x k, column-major) factorised side by side: sums[j], rcs[j] = MCML_OK | MCML_ENOTPD
 int mvn_loglik_batch(Ctx& c, const double* thetas, int k, const double* U, int ldu, int m, double* sums, int* rcs);
 // L = genD(0, chol=true, upper=false) (mcml_full.cpp:68): block-diagonal lower factor
 int mvn_gen_L(Ctx& c, const double* theta, bool chol);

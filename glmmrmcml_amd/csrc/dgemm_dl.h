@@ -139,8 +139,11 @@ __global__ __launch_bounds__(64 * WM * WN) void dgemm_dl_kernel(GemmP p, Epi epi
         }
     }
     const size_t stepA = (size_t)BK * p.lda * 8, stepB = BNMAJOR ? (size_t)BK * p.ldb * 8 : (size_t)BK * 8;
-    const char* sA = reinterpret_cast<const char*>(p.A);
-    const char* sB = reinterpret_cast<const char*>(p.B);
+    // blockIdx.y: one of several independent problems of the same shape (the candidate thetas of a theta-step round
+    // factorised side by side, mvn.hip)
+    const int by = blockIdx.y;
+    const char* sA = reinterpret_cast<const char*>(p.A + (size_t)by * p.bsA);
+    const char* sB = reinterpret_cast<const char*>(p.B + (size_t)by * p.bsB);
 
     auto issue = [&](int stage) {
         const unsigned lbase = (unsigned)(size_t)(lds_ptr_t)lds + stage * Cfg::STAGE_BYTES;
@@ -201,7 +204,9 @@ __global__ __launch_bounds__(64 * WM * WN) void dgemm_dl_kernel(GemmP p, Epi epi
         st = st + 1; if (st >= STAGES) st = 0;
     }
 
-    epi(acc, m0 + wr * 16 * WTM, n0 + wc * 16 * WTN, lane, p.M, p.N, bi * WM + wr);
+    Epi e = epi;
+    e.shift(by);
+    e(acc, m0 + wr * 16 * WTM, n0 + wc * 16 * WTN, lane, p.M, p.N, bi * WM + wr);
 }
 
 static inline bool dl_applicable(int M, int N, int K, const double* A, int lda, const double* B, int ldb,
@@ -213,7 +218,7 @@ static inline bool dl_applicable(int M, int N, int K, const double* A, int lda, 
 }
 
 template <int WTM, int WTN, int WM, int WN, bool BNMAJOR, int STAGES, class Epi>
-static inline int launch_gemm_dl_cfg(hipStream_t s, GemmP p, const Epi& epi)
+static inline int launch_gemm_dl_cfg(hipStream_t s, GemmP p, const Epi& epi, int nbatch = 1)
 {
     using Cfg = DlgCfg<WTM, WTN, WM, WN, BNMAJOR, STAGES>;
     p.gm = (p.M + Cfg::BM - 1) / Cfg::BM;
@@ -227,7 +232,7 @@ static inline int launch_gemm_dl_cfg(hipStream_t s, GemmP p, const Epi& epi)
         }
     }
     MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&dgemm_dl_kernel<WTM, WTN, WM, WN, BNMAJOR, STAGES, Epi>), (int)Cfg::LDS_BYTES));
-    hipLaunchKernelGGL((dgemm_dl_kernel<WTM, WTN, WM, WN, BNMAJOR, STAGES, Epi>), dim3((unsigned)ntiles),
+    hipLaunchKernelGGL((dgemm_dl_kernel<WTM, WTN, WM, WN, BNMAJOR, STAGES, Epi>), dim3((unsigned)ntiles, (unsigned)nbatch),
                        dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, p, epi);
     MCML_HIP(hipGetLastError());
     return MCML_OK;
@@ -244,11 +249,11 @@ static inline int launch_gemm_dl_cfg(hipStream_t s, GemmP p, const Epi& epi)
 template <bool BNMAJOR, class Epi>
 static inline int launch_gemm_dl(hipStream_t s, int M, int N, int K, const double* A, int lda,
                                  const double* B, int ldb, const Epi& epi, bool lower_only = false, int tile = 0,
-                                 int inplace = 0, int diag_shift = 0)
+                                 int inplace = 0, int diag_shift = 0, int nbatch = 1, size_t bsA = 0, size_t bsB = 0)
 {
     MCML_REQUIRE(dl_applicable(M, N, K, A, lda, B, ldb, BNMAJOR), "dgemm_dl: shape/alignment contract violated "
                  "(M %d N %d K %d lda %d ldb %d)", M, N, K, lda, ldb);
-    GemmP p{M, N, K, A, lda, B, ldb, 0, 0, lower_only ? 1 : 0, 0, diag_shift};
+    GemmP p{M, N, K, A, lda, B, ldb, 0, 0, lower_only ? 1 : 0, 0, diag_shift, bsA, bsB};
     if (tile == 0) {
         long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
         if (lower_only) t128 = t128 / 2 + (M + 127) / 128;
@@ -263,14 +268,14 @@ static inline int launch_gemm_dl(hipStream_t s, int M, int N, int K, const doubl
     MCML_REQUIRE(!(inplace == 1 && (tile == 6 || tile == 8) && N > (tile == 6 ? 64 : 32)) &&
                  !(inplace == 2 && (tile == 2 || tile == 5 || tile == 6 || tile == 7 || tile == 8) && M > (tile == 7 ? 16 : tile == 8 ? 32 : 64)),
                  "dgemm_dl: tile %d cannot run this product in place", tile);
-    if (tile == 1) return launch_gemm_dl_cfg<4, 2, 2, 4, BNMAJOR, 4, Epi>(s, p, epi);
-    if (tile == 3) return launch_gemm_dl_cfg<1, 2, 8, 1, BNMAJOR, 6, Epi>(s, p, epi);
-    if (tile == 4) return launch_gemm_dl_cfg<4, 2, 2, 4, BNMAJOR, 2, Epi>(s, p, epi);
-    if (tile == 5) return launch_gemm_dl_cfg<2, 2, 2, 4, BNMAJOR, 3, Epi>(s, p, epi);
-    if (tile == 6) return launch_gemm_dl_cfg<2, 2, 2, 2, BNMAJOR, 3, Epi>(s, p, epi);
-    if (tile == 7) return launch_gemm_dl_cfg<1, 2, 1, 4, BNMAJOR, 4, Epi>(s, p, epi);    // 16 x 128, 4 waves
-    if (tile == 8) return launch_gemm_dl_cfg<1, 1, 2, 2, BNMAJOR, 4, Epi>(s, p, epi);    // 32 x 32, 4 waves
-    return launch_gemm_dl_cfg<2, 2, 2, 4, BNMAJOR, 5, Epi>(s, p, epi);
+    if (tile == 1) return launch_gemm_dl_cfg<4, 2, 2, 4, BNMAJOR, 4, Epi>(s, p, epi, nbatch);
+    if (tile == 3) return launch_gemm_dl_cfg<1, 2, 8, 1, BNMAJOR, 6, Epi>(s, p, epi, nbatch);
+    if (tile == 4) return launch_gemm_dl_cfg<4, 2, 2, 4, BNMAJOR, 2, Epi>(s, p, epi, nbatch);
+    if (tile == 5) return launch_gemm_dl_cfg<2, 2, 2, 4, BNMAJOR, 3, Epi>(s, p, epi, nbatch);
+    if (tile == 6) return launch_gemm_dl_cfg<2, 2, 2, 2, BNMAJOR, 3, Epi>(s, p, epi, nbatch);
+    if (tile == 7) return launch_gemm_dl_cfg<1, 2, 1, 4, BNMAJOR, 4, Epi>(s, p, epi, nbatch);    // 16 x 128, 4 waves
+    if (tile == 8) return launch_gemm_dl_cfg<1, 1, 2, 2, BNMAJOR, 4, Epi>(s, p, epi, nbatch);    // 32 x 32, 4 waves
+    return launch_gemm_dl_cfg<2, 2, 2, 4, BNMAJOR, 5, Epi>(s, p, epi, nbatch);
 }
 
 }  // namespace mcml

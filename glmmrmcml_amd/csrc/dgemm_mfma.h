@@ -42,6 +42,7 @@ struct GemmP {
     int lower_only;             // skip tiles that lie strictly above the diagonal
     int dbg_nostep;             // timing experiment only: do not advance the operand pointers
     int diag_shift = 0;         // dgemm_dl lower_only: row m of C is row m + diag_shift of the square matrix
+    size_t bsA = 0, bsB = 0;    // dgemm_dl batches (blockIdx.y): element strides of A and B from one problem to the next
 };
 
 // WTM x WTN: 16x16 MFMA tiles per wave; WM x WN: waves per workgroup.
@@ -69,6 +70,8 @@ struct GemmCfg {
 
 struct EpiAxpby {   // C = alpha*A*B + beta*C
     double* C; int ldc; double alpha, beta;
+    size_t bsC = 0;                                              // dgemm_dl batches: element stride of C
+    __device__ __forceinline__ void shift(int b) { C += (size_t)b * bsC; }
     // With beta != 0 all reads of C are issued (from clamped, always valid addresses) before the first
     // store: a store to C followed by a load from C cannot be reordered by the compiler (may alias), so the
     // straightforward per-element read-modify-write is a chain of dependent memory round trips.

@@ -112,6 +112,7 @@ struct McmlOptim {
                 for (size_t q = 0; q < own.size(); ++q) {
                     const int j = own[q];
                     const int rc = (rcs[q] == MCML_OK && brc != MCML_OK) ? brc : rcs[q];
+                    if (rc != MCML_OK && getenv("GLMMR_MCML_BOBYQA_TRACE")) fprintf(stderr, "theta-step: candidate %d (theta %.6g %.6g) rc %d brc %d: %s\n", j, ths[q * R], R > 1 ? ths[q * R + 1] : 0.0, rcs[q], brc, last_error());
                     if (rc == MCML_ENOTPD) vals[j] = HUGE_VAL;               // as eval_mvn: infinitely bad, not an error
                     else if (rc != MCML_OK) { vals[j] = NAN; if (first_rc == MCML_OK) first_rc = rc; }
                     else vals[j] = -1 * (sums[q] / mall);
@@ -151,7 +152,17 @@ struct McmlOptim {
     {
         static const bool shard = !(getenv("GLMMR_MCML_THETA_SHARD") && !strcmp(getenv("GLMMR_MCML_THETA_SHARD"), "0"));
         const int wr = comm_world(c);
-        if ((wr > 1 && shard) || theta_batch > 1) return d_optim_sharded(wr * std::max(1, theta_batch));
+        // candidates per rank and round.  A model whose D is large dense blocks only (the geospatial configs) evaluates
+        // a round's candidates in ONE pass of the factorisation's schedule (mvn.hip mvn_loglik_batch): there the batch
+        // schedule is the default even for a single process -- 8 candidates per round, 2 per rank of a sharded job
+        // (GLMMR_MCML_THETA_BATCH overrides, 1 = the reference's sequential BOBYQA).  glmmr_mcml_ext.theta_batch wins.
+        int k = theta_batch;
+        if (k <= 0) {
+            static const int envk = getenv("GLMMR_MCML_THETA_BATCH") ? atoi(getenv("GLMMR_MCML_THETA_BATCH")) : 0;
+            const bool dense_only = c.maxdim_large > 0 && c.n_small == 0 && c.n_diag_rows == 0;
+            k = envk > 0 ? envk : dense_only ? (wr > 1 ? 2 : 8) : 1;
+        }
+        if ((wr > 1 && shard) || k > 1) return d_optim_sharded(wr * std::max(1, k));
         objective_fn f = [&](const std::vector<double>& par, double* v) {
             double logl; MCML_TRY(eval_mvn(c, par.data(), &logl)); *v = -1 * logl; return (int)MCML_OK; };
         std::vector<double> lo(R, 1e-6), up(R, HUGE_VAL);

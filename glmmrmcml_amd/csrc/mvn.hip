@@ -156,9 +156,31 @@ __global__ __launch_bounds__(64) void k_small_ll(const double* U, int ldu, int m
 // (dpad > dim: rows / columns dim .. dpad are an identity border, so that an odd block can be factorised as an
 // even one -- every panel pointer stays 16-byte aligned; the border does not change L, the log-determinant or
 // the solves)
+// the candidate thetas of one round (mvn_loglik_batch): blockIdx.z picks the candidate and its matrix
+constexpr int MVN_MAXBATCH = 8;
+struct ThetaBatch { ThetaArg t[MVN_MAXBATCH]; };
+
+template <class TH>
+__device__ __forceinline__ void build_dense_body(double* A, int lda, int bidx, const CovBlock* blocks, const int32_t* cov,
+                                                 int rows, const double* data, const TH& th, int mirror, int dpad);
+
+__global__ __launch_bounds__(256) void k_build_dense_batch(double* A, int lda, size_t bsA, int bidx, const CovBlock* blocks,
+                                                           const int32_t* cov, int rows, const double* data,
+                                                           ThetaBatch tb, int dpad)
+{
+    build_dense_body(A + (size_t)blockIdx.z * bsA, lda, bidx, blocks, cov, rows, data, tb.t[blockIdx.z], 0, dpad);
+}
+
 __global__ __launch_bounds__(256) void k_build_dense(double* A, int lda, int bidx, const CovBlock* blocks,
                                                      const int32_t* cov, int rows, const double* data,
                                                      ThetaArg th, int mirror, int dpad)
+{
+    build_dense_body(A, lda, bidx, blocks, cov, rows, data, th, mirror, dpad);
+}
+
+template <class TH>
+__device__ __forceinline__ void build_dense_body(double* A, int lda, int bidx, const CovBlock* blocks, const int32_t* cov,
+                                                 int rows, const double* data, const TH& th, int mirror, int dpad)
 {
     // a workgroup = 64 rows x 16 columns, a wave = the 64 rows of four columns: every store is 512 contiguous bytes
     // (16 x 16 tiles with 128-byte row groups ran 71 us for the 5000 x 5000 lower triangle)
@@ -257,9 +279,11 @@ __device__ __forceinline__ void leaf_sync()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __global__ __launch_bounds__(LEAF_NT) void k_potrf_leaf(double* A, int lda, int n, double* Linv, int* errflag,
-                                                    unsigned long long* prof)
+                                                    unsigned long long* prof, size_t bsA = 0, size_t bsL = 0)
 {
 #pragma clang fp contract(fast)      // the factorisation is not part of the bit-exact RNG / leapfrog contract
+    // blockIdx.x: one of several matrices factorised side by side (mvn_loglik_batch), each with its own flag
+    A += (size_t)blockIdx.x * bsA; Linv += (size_t)blockIdx.x * bsL; errflag += blockIdx.x;
 #define LEAF_T(i) do { if (prof && threadIdx.x == 0) prof[i] = __builtin_amdgcn_s_memtime(); } while (0)
     LEAF_T(0);
     extern __shared__ __attribute__((aligned(16))) double S[];
@@ -498,8 +522,10 @@ int potrf_leaf_profile(Ctx& c, unsigned long long* host10)
 }
 
 // AT (cols x rows) = A' through a 32 x 33 LDS tile
-__global__ __launch_bounds__(256) void k_transpose_in(const double* A, int lda, int rows, int cols, double* AT, int ldt)
+__global__ __launch_bounds__(256) void k_transpose_in(const double* A, int lda, int rows, int cols, double* AT, int ldt,
+                                                      size_t bsT = 0)
 {
+    AT += (size_t)blockIdx.z * bsT;            // the same samples under every candidate's matrix
     __shared__ double tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -672,24 +698,32 @@ static int lookahead_setup(Ctx& c)
 // + max(bulk, leaf).  (A freer two-queue schedule measured ~10 % faster live but
 // hung intermittently; it exists as a captured graph only -- see "the hang" above potrf_la2_capture.)
 //   GLMMR_MCML_CHOL=rec : the recursive variant;  =nola : everything on one stream
-static int potrf_blocked(Ctx& c, double* A, int lda, int n, int extra)
+// Several matrices of the same shape factorised side by side (the candidate thetas of one theta-step round): every
+// launch of the schedule covers all of them (leaf: one workgroup per matrix; products: blockIdx.y), so the latency
+// chain of the late steps -- leaf, two single-block products, their gaps -- is paid once per round, not once per
+// candidate.  sA / sL: element strides from one matrix / one set of inverted diagonal blocks to the next.
+struct Bat { int n = 1; size_t sA = 0, sL = 0; int* err = nullptr; };   // err: one flag per matrix (null: the context's own)
+
+static int potrf_blocked(Ctx& c, double* A, int lda, int n, int extra, Bat bt = Bat())
 {
-    int* errflag = c.scalars.as<int>() + 32;
+    int* errflag = bt.err ? bt.err : c.scalars.as<int>() + 32;
     const bool two = chol_mode() == 1 && n > 2 * CHOL_NB;
     hipStream_t sM = c.stream, sL = c.stream;
     if (two) { MCML_TRY(lookahead_setup(c)); sL = c.aux; }
     auto leaf = [&](hipStream_t s, int k, int nb) -> int {
-        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(LEAF_NT), POTRF_LDS, s, A + k + (size_t)k * lda, lda, nb,
-                           c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB, errflag, nullptr);
+        hipLaunchKernelGGL(k_potrf_leaf, dim3(bt.n), dim3(LEAF_NT), POTRF_LDS, s, A + k + (size_t)k * lda, lda, nb,
+                           c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB, errflag, nullptr, bt.sA, bt.sL);
         MCML_HIP(hipGetLastError());
         return MCML_OK;
     };
     // C (M x N) = alpha A B' + beta C with B N-major, preferring the LDS-DMA kernel with a given tile
     auto gemm_nt = [&](int M, int N, int K, const double* Ap, const double* Bp, int ldb, double* Cp,
                        double alpha, double beta, bool lower, int tile, int inplace, int shift) -> int {
-        EpiAxpby epi{Cp, lda, alpha, beta};
+        EpiAxpby epi{Cp, lda, alpha, beta, bt.sA};
+        const size_t sB = (ldb == CHOL_NB) ? bt.sL : bt.sA;            // B is an inverted diagonal block, or part of the matrix
         if (dl_applicable(M, N, K, Ap, lda, Bp, ldb, true))
-            return launch_gemm_dl<true>(sM, M, N, K, Ap, lda, Bp, ldb, epi, lower, tile, inplace, shift);
+            return launch_gemm_dl<true>(sM, M, N, K, Ap, lda, Bp, ldb, epi, lower, tile, inplace, shift, bt.n, bt.sA, sB);
+        MCML_REQUIRE(bt.n == 1, "potrf: a batch of factorisations needs the LDS-DMA kernel for every panel product");
         MCML_REQUIRE(shift == 0 || !lower, "potrf: shifted lower-only update needs the LDS-DMA kernel");
         return launch_gemm<true>(sM, M, N, K, Ap, lda, Bp, ldb, epi, lower, inplace ? inplace : -1);
     };
@@ -768,21 +802,23 @@ static hipEvent_t ring_event(Ctx& c, size_t idx)
     }
     return c.ev_ring[idx];
 }
-static int potrf_la2_capture(Ctx& c, double* A, int lda, int n, int extra)
+static int potrf_la2_capture(Ctx& c, double* A, int lda, int n, int extra, Bat bt = Bat())
 {
-    int* errflag = c.scalars.as<int>() + 32;
+    int* errflag = bt.err ? bt.err : c.scalars.as<int>() + 32;
     hipStream_t sC = c.stream, sB = c.aux_lo;
     auto leaf = [&](int k, int nb) -> int {
-        hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(LEAF_NT), POTRF_LDS, sC, A + k + (size_t)k * lda, lda, nb,
-                           c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB, errflag, nullptr);
+        hipLaunchKernelGGL(k_potrf_leaf, dim3(bt.n), dim3(LEAF_NT), POTRF_LDS, sC, A + k + (size_t)k * lda, lda, nb,
+                           c.linv.d() + (size_t)(k / CHOL_NB) * CHOL_NB * CHOL_NB, errflag, nullptr, bt.sA, bt.sL);
         MCML_HIP(hipGetLastError());
         return MCML_OK;
     };
     auto gemm_nt = [&](hipStream_t st, int M, int N, int K, const double* Ap, const double* Bp, int ldb, double* Cp,
                        double alpha, double beta, bool lower, int tile, int inplace) -> int {
-        EpiAxpby epi{Cp, lda, alpha, beta};
+        EpiAxpby epi{Cp, lda, alpha, beta, bt.sA};
+        const size_t sBb = (ldb == CHOL_NB) ? bt.sL : bt.sA;
         if (dl_applicable(M, N, K, Ap, lda, Bp, ldb, true))
-            return launch_gemm_dl<true>(st, M, N, K, Ap, lda, Bp, ldb, epi, lower, tile, inplace, 0);
+            return launch_gemm_dl<true>(st, M, N, K, Ap, lda, Bp, ldb, epi, lower, tile, inplace, 0, bt.n, bt.sA, sBb);
+        MCML_REQUIRE(bt.n == 1, "potrf: a batch of factorisations needs the LDS-DMA kernel for every panel product");
         return launch_gemm<true>(st, M, N, K, Ap, lda, Bp, ldb, epi, lower, inplace ? inplace : -1);
     };
     const int nsteps = (n + CHOL_NB - 1) / CHOL_NB;
@@ -857,19 +893,19 @@ static int chol_graph_kind()
     return v;
 }
 static bool chol_graph_on() { return chol_graph_kind() != 0; }
-static int potrf_graphed(Ctx& c, double* A, int lda, int n, int extra)
+static int potrf_graphed(Ctx& c, double* A, int lda, int n, int extra, Bat bt = Bat())
 {
-    if (!chol_graph_on() || !(chol_mode() == 1 && n > 2 * CHOL_NB)) return potrf_blocked(c, A, lda, n, extra);
-    CholGraph& g = c.chol_graphs.find(A, c.linv.d(), lda, n, extra);
+    if (!chol_graph_on() || !(chol_mode() == 1 && n > 2 * CHOL_NB)) return potrf_blocked(c, A, lda, n, extra, bt);
+    CholGraph& g = c.chol_graphs.find(A, c.linv.d(), lda, n, extra + (bt.n << 24));
     if (g.exec) { MCML_HIP(hipGraphLaunch(g.exec, c.stream)); return MCML_OK; }
-    if (g.seen++ <= 0) return potrf_blocked(c, A, lda, n, extra);          // eager first: attributes, allocations
+    if (g.seen++ <= 0) return potrf_blocked(c, A, lda, n, extra, bt);      // eager first: attributes, allocations
     MCML_TRY(lookahead_setup(c));
     if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();                                           // e.g. the legacy default stream: eager for good
         g.seen = -(1 << 30);
-        return potrf_blocked(c, A, lda, n, extra);
+        return potrf_blocked(c, A, lda, n, extra, bt);
     }
-    const int rc = chol_graph_kind() == 2 ? potrf_la2_capture(c, A, lda, n, extra) : potrf_blocked(c, A, lda, n, extra);
+    const int rc = chol_graph_kind() == 2 ? potrf_la2_capture(c, A, lda, n, extra, bt) : potrf_blocked(c, A, lda, n, extra, bt);
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(c.stream, &graph);
     if (rc != MCML_OK || e != hipSuccess || !graph) {
@@ -877,14 +913,14 @@ static int potrf_graphed(Ctx& c, double* A, int lda, int n, int extra)
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
         g.seen = -(1 << 30);
-        return potrf_blocked(c, A, lda, n, extra);
+        return potrf_blocked(c, A, lda, n, extra, bt);
     }
     const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) {
         (void)hipGetLastError();
         g.exec = nullptr; g.seen = -(1 << 30);
-        return potrf_blocked(c, A, lda, n, extra);
+        return potrf_blocked(c, A, lda, n, extra, bt);
     }
     MCML_HIP(hipGraphLaunch(g.exec, c.stream));
     return MCML_OK;
@@ -1034,63 +1070,85 @@ int mvn_loglik_sum_on(Ctx& c, const double* theta, const double* Us, int ldu, in
     return MCML_OK;
 }
 
-static void lane_swap(Ctx& c, MvnLane& l)
-{
-    std::swap(c.stream, l.stream); std::swap(c.aux, l.aux); std::swap(c.aux_lo, l.aux_lo);
-    std::swap(c.ev_col, l.ev_col); std::swap(c.ev_leaf, l.ev_leaf); std::swap(c.ev_ps, l.ev_ps); std::swap(c.ev_b, l.ev_b);
-    std::swap(c.Dwork, l.Dwork); std::swap(c.Uwork, l.Uwork);
-    std::swap(c.linv, l.linv); std::swap(c.partials, l.partials); std::swap(c.scalars, l.scalars); std::swap(c.scratch, l.scratch);
-    std::swap(c.chol_graphs, l.chol_graphs); std::swap(c.ev_ring, l.ev_ring);
-}
-
-// Candidate j runs on lane j: the same launches as mvn_loglik_sum_on, on the lane's stream and workspaces, with no
-// host synchronisation until every candidate has been enqueued.
+// k candidate thetas in ONE pass of the factorisation's schedule.  A single evaluation of a large dense block is a
+// latency chain (40 steps of leaf + two single-block products, ~70 us each, on a handful of CUs; 0.24 of the FP64 MFMA
+// peak at Q = 5000); with the k matrices side by side in one workspace every launch covers all of them, so the chain
+// is paid once per round.  (Measured dead end: the k evaluations as k independent streams / graphs -- "lanes" -- do
+// not overlap on this stack: 3.6 ms per evaluation alone, 4.1 / 4.8 / 5.0 ms each with 2 / 4 / 8 lanes, worse with
+// more hardware queues.)  Models whose D has diagonal or small blocks besides, and k = 1, take the single path.
 int mvn_loglik_batch(Ctx& c, const double* thetas, int k, const double* Us, int ldu, int m, double* sums, int* rcs)
 {
-    MCML_REQUIRE(k >= 1 && thetas && sums && rcs, "mvn_ll batch: bad arguments");
-    const int R = c.cov.npar;
-    if (k == 1) {                         // nothing to run beside it: the context's own stream and workspace
-        rcs[0] = mvn_loglik_sum_on(c, thetas, Us, ldu, m, sums);
-        if (rcs[0] == MCML_ENOTPD) return MCML_OK;
-        return rcs[0];
-    }
-    while ((int)c.lanes.size() < k) {
-        std::unique_ptr<MvnLane> l(new MvnLane());
-        MCML_HIP(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
-        MCML_TRY(l->scalars.ensure(sizeof(double) * 64));
-        MCML_HIP(hipMemsetAsync(l->scalars.p, 0, sizeof(double) * 64, l->stream));
-        MCML_HIP(hipHostMalloc(reinterpret_cast<void**>(&l->host), sizeof(double) * 2, hipHostMallocDefault));
-        MCML_HIP(hipStreamSynchronize(l->stream));
-        c.lanes.push_back(std::move(l));
-    }
-    if (!c.ev_lanes) MCML_HIP(hipEventCreateWithFlags(&c.ev_lanes, hipEventDisableTiming));
-    MCML_HIP(hipEventRecord(c.ev_lanes, c.stream));              // the samples are where the lanes will read them
-    int first_rc = MCML_OK;
-    for (int j = 0; j < k; ++j) {
-        MvnLane& l = *c.lanes[j];
-        MCML_HIP(hipStreamWaitEvent(l.stream, c.ev_lanes, 0));
-        lane_swap(c, l);
-        int rc = mvn_loglik_enqueue(c, thetas + (size_t)j * R, Us, ldu, m);
-        if (rc == MCML_OK) {
-            hipError_t e = hipMemcpyAsync(l.host, c.scalars.d(), sizeof(double), hipMemcpyDeviceToHost, c.stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(l.host + 1, c.scalars.as<int>() + 32, sizeof(int), hipMemcpyDeviceToHost, c.stream);
-            if (e == hipSuccess) e = hipMemsetAsync(c.scalars.as<int>() + 32, 0, sizeof(int), c.stream);
-            if (e != hipSuccess) { set_error("mvn_ll batch: %s", hipGetErrorString(e)); rc = MCML_EHIP; }
+    MCML_REQUIRE(k >= 1 && thetas && sums && rcs && m > 0 && Us, "mvn_ll batch: bad arguments");
+    const CovSpec& cs = c.cov;
+    const int R = cs.npar;
+    static const bool off = getenv("GLMMR_MCML_MVN_BATCH") && !strcmp(getenv("GLMMR_MCML_MVN_BATCH"), "0");
+    const bool batchable = !off && k > 1 && c.maxdim_large > 0 && c.n_small == 0 && c.n_diag_rows == 0 && chol_blocked();
+    if (!batchable) {
+        int first_rc = MCML_OK;
+        for (int j = 0; j < k; ++j) {
+            rcs[j] = mvn_loglik_sum_on(c, thetas + (size_t)j * R, Us, ldu, m, sums + j);
+            if (rcs[j] != MCML_OK && rcs[j] != MCML_ENOTPD && first_rc == MCML_OK) first_rc = rcs[j];
         }
-        lane_swap(c, l);
-        rcs[j] = rc;
-        if (rc != MCML_OK && first_rc == MCML_OK) first_rc = rc;
+        return first_rc;
     }
-    for (int j = 0; j < k; ++j) {
-        MvnLane& l = *c.lanes[j];
-        const hipError_t e = hipStreamSynchronize(l.stream);
-        if (e != hipSuccess && first_rc == MCML_OK) { set_error("mvn_ll batch: %s", hipGetErrorString(e)); first_rc = MCML_EHIP; }
-        if (rcs[j] != MCML_OK) continue;
-        sums[j] = l.host[0];
-        int flag; memcpy(&flag, l.host + 1, sizeof(int));
-        if (flag) rcs[j] = MCML_ENOTPD;
+    for (int j0 = 0; j0 < k; j0 += MVN_MAXBATCH) {
+        const int kb = (k - j0 < MVN_MAXBATCH) ? k - j0 : MVN_MAXBATCH;
+        ThetaBatch tb;
+        memset(&tb, 0, sizeof tb);
+        for (int j = 0; j < kb; ++j)
+            for (int i = 0; i < R; ++i) tb.t[j].v[i] = thetas[(size_t)(j0 + j) * R + i];
+        const int dmax = round_up(c.maxdim_large, 16);
+        // kb matrices side by side: matrix j = columns [j * dmax, (j + 1) * dmax), the m sample rows below each
+        if (c.Dbatch.rows < dmax + m || c.Dbatch.cols < kb * dmax) {
+            MCML_TRY(c.Dbatch.alloc(dmax + m, MVN_MAXBATCH * dmax));
+            MCML_HIP(hipMemsetAsync(c.Dbatch.d(), 0, sizeof(double) * (size_t)c.Dbatch.ld * MVN_MAXBATCH * dmax, c.stream));
+        }
+        const int ld = c.Dbatch.ld;
+        const size_t sA = (size_t)ld * dmax;
+        const int nst = dmax / CHOL_NB + 1;
+        const size_t sL = (size_t)nst * CHOL_NB * CHOL_NB;
+        MCML_TRY(c.linv.ensure(sizeof(double) * sL * MVN_MAXBATCH));
+        // results: 4 doubles per candidate, then one "not positive definite" flag (int) per candidate -- a buffer of
+        // their own (c.scalars is shared with the sampler's diagnostics)
+        MCML_TRY(c.bscal.ensure(sizeof(double) * 5 * MVN_MAXBATCH));
+        MCML_HIP(hipMemsetAsync(c.bscal.p, 0, sizeof(double) * 5 * MVN_MAXBATCH, c.stream));
+        int* bflags = reinterpret_cast<int*>(c.bscal.d() + 4 * MVN_MAXBATCH);
+        const int32_t* dcov = c.d_cov.as<int32_t>();
+        const CovBlock* dblk = c.d_blocks.as<CovBlock>();
+        for (int b = 0; b < cs.B; ++b) {
+            const CovBlock& blk = cs.blocks[b];
+            const int d = blk.dim, dp = round_up(d, 16);
+            hipLaunchKernelGGL(k_build_dense_batch, dim3((dp + 63) / 64, (dp + 15) / 16, kb), dim3(256), 0, c.stream,
+                               c.Dbatch.d(), ld, sA, b, dblk, dcov, cs.rows, c.d_data.d(), tb, dp);
+            hipLaunchKernelGGL(k_transpose_in, dim3((d + 31) / 32, (m + 31) / 32, kb), dim3(256), 0, c.stream,
+                               Us + blk.matstart, ldu, d, m, c.Dbatch.d() + dp, ld, sA);
+            MCML_HIP(hipGetLastError());
+            if (dp > d)          // the border columns of the sample rows must be finite: they meet zeros only
+                for (int j = 0; j < kb; ++j)
+                    MCML_HIP(hipMemset2DAsync(c.Dbatch.d() + j * sA + dp + (size_t)d * ld, sizeof(double) * ld, 0, sizeof(double) * m, dp - d, c.stream));
+            MCML_HIP(hipMemsetAsync(c.linv.p, 0, sizeof(double) * sL * kb, c.stream));
+            MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_potrf_leaf), (int)POTRF_LDS));
+            Bat bt; bt.n = kb; bt.sA = sA; bt.sL = sL; bt.err = bflags;
+            MCML_TRY(potrf_graphed(c, c.Dbatch.d(), ld, dp, m, bt));
+            const int gx = (m + 255) / 256, gy = d < 64 ? d : 64;
+            MCML_TRY(c.partials.ensure(sizeof(double) * (size_t)(gx * gy + 16)));
+            for (int j = 0; j < kb; ++j) {
+                double* scal = c.bscal.d() + 4 * j;
+                const double* Aj = c.Dbatch.d() + j * sA;
+                hipLaunchKernelGGL(k_sumsq, dim3(gx, gy), dim3(256), 0, c.stream, Aj + dp, ld, m, d, c.partials.d());
+                hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, c.partials.d(), gx * gy, 1.0, scal + 2, 0);
+                hipLaunchKernelGGL(k_logdet, dim3(1), dim3(256), 0, c.stream, Aj, ld, d, scal + 1);
+                hipLaunchKernelGGL(k_finish_large, dim3(1), dim3(1), 0, c.stream, scal, d, m);
+            }
+            MCML_HIP(hipGetLastError());
+        }
+        double hs[4 * MVN_MAXBATCH]; int hf[MVN_MAXBATCH];
+        MCML_HIP(hipMemcpyAsync(hs, c.bscal.p, sizeof(double) * 4 * kb, hipMemcpyDeviceToHost, c.stream));
+        MCML_HIP(hipMemcpyAsync(hf, bflags, sizeof(int) * kb, hipMemcpyDeviceToHost, c.stream));
+        MCML_HIP(hipStreamSynchronize(c.stream));
+        for (int j = 0; j < kb; ++j) { sums[j0 + j] = hs[4 * j]; rcs[j0 + j] = hf[j] ? MCML_ENOTPD : MCML_OK; }
     }
-    return first_rc;
+    return MCML_OK;
 }
 
 static int mvn_loglik_enqueue(Ctx& c, const double* theta, const double* Us, int ldu, int m)
@@ -1142,9 +1200,9 @@ static int mvn_loglik_enqueue(Ctx& c, const double* theta, const double* Us, int
         // the forward substitution happens inside the factorisation (potrf_blocked); recursive path: separate TRSM
         const bool aug = chol_blocked();
         if (aug) {
-            if (c.Dwork.rows < c.maxdim_large + 2 + m || c.Dwork.cols < c.maxdim_large + 2) {
-                MCML_TRY(c.Dwork.alloc(c.maxdim_large + 2 + m, c.maxdim_large + 2));
-                MCML_HIP(hipMemsetAsync(c.Dwork.d(), 0, sizeof(double) * (size_t)c.Dwork.ld * (c.maxdim_large + 2), c.stream));
+            if (c.Dwork.rows < c.maxdim_large + 16 + m || c.Dwork.cols < c.maxdim_large + 16) {
+                MCML_TRY(c.Dwork.alloc(c.maxdim_large + 16 + m, c.maxdim_large + 16));
+                MCML_HIP(hipMemsetAsync(c.Dwork.d(), 0, sizeof(double) * (size_t)c.Dwork.ld * (c.maxdim_large + 16), c.stream));
             }
         } else {
             MCML_TRY(c.Uwork.alloc(c.maxdim_large, m));
@@ -1154,7 +1212,9 @@ static int mvn_loglik_enqueue(Ctx& c, const double* theta, const double* Us, int
             if (blk.all_gr || blk.dim <= SMALL_BLOCK) continue;
             const int d = blk.dim;
             dim3 g((d + 15) / 16, (d + 15) / 16);
-            const int dp = aug ? round_up(d, 2) : d;      // even: the extra rows and every panel stay 16-byte aligned
+            // a multiple of 16 (identity border): the extra rows and every panel stay 16-byte aligned and the last, ragged
+            // panel still has a K the LDS-DMA kernel takes (5000 = 39 x 128 + 8 would fall back to the register-staged one)
+            const int dp = aug ? round_up(d, 16) : d;
             g = dim3((dp + 63) / 64, (dp + 15) / 16);
             hipLaunchKernelGGL(k_build_dense, g, dim3(256), 0, c.stream, c.Dwork.d(), c.Dwork.ld, b, dblk, dcov,
                                cs.rows, c.d_data.d(), th, 0, dp);
@@ -1163,8 +1223,8 @@ static int mvn_loglik_enqueue(Ctx& c, const double* theta, const double* Us, int
             if (aug) {
                 hipLaunchKernelGGL(k_transpose_in, dim3((d + 31) / 32, (m + 31) / 32), dim3(256), 0, c.stream,
                                    Us + blk.matstart, ldu, d, m, c.Dwork.d() + dp, c.Dwork.ld);
-                if (dp > d)        // the border column of the sample rows must be finite: it meets zeros only
-                    MCML_HIP(hipMemsetAsync(c.Dwork.d() + dp + (size_t)d * c.Dwork.ld, 0, sizeof(double) * m, c.stream));
+                if (dp > d)        // the border columns of the sample rows must be finite: they meet zeros only
+                    MCML_HIP(hipMemset2DAsync(c.Dwork.d() + dp + (size_t)d * c.Dwork.ld, sizeof(double) * c.Dwork.ld, 0, sizeof(double) * m, dp - d, c.stream));
                 MCML_HIP(hipGetLastError());
                 MCML_TRY(c.linv.ensure(sizeof(double) * (size_t)(dp / CHOL_NB + 1) * CHOL_NB * CHOL_NB));
                 MCML_HIP(hipMemsetAsync(c.linv.p, 0, sizeof(double) * (size_t)((dp + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB, c.stream));

@@ -541,6 +541,7 @@ private:
     vec F_;
     Quad q_;
     std::vector<double> Winv_; double sc_ = 1.0;   // inverse KKT matrix in coordinates (x - xb)/sc
+    double fin_lo_ = HUGE_VAL, fin_hi_ = -HUGE_VAL; // range of the finite objective values seen (eval_batch)
 
     double eval(const vec& x)
     {
@@ -566,7 +567,14 @@ private:
         nf_ += (int)X.size();
         if (rc) { rc_ = rc; return false; }
         if (F->size() != X.size()) { rc_ = MCML_EINVAL; set_error("bobyqa_batch: objective returned %zu values for %zu points", F->size(), X.size()); return false; }
-        for (double& v : *F) if (v != v) v = HUGE_VAL;
+        // A point with no value (NaN, +inf: e.g. a covariance matrix that is not positive definite there) must stay
+        // "worse than anything seen" without poisoning the interpolation models with infinities: it gets the largest
+        // finite value seen so far plus ten times the spread of the finite values
+        for (double v : *F) if (std::isfinite(v)) { fin_lo_ = std::min(fin_lo_, v); fin_hi_ = std::max(fin_hi_, v); }
+        for (double& v : *F)
+            if (!std::isfinite(v)) {
+                v = (fin_hi_ >= fin_lo_) ? fin_hi_ + 10.0 * std::max(1.0, fin_hi_ - fin_lo_) : 1e30;
+            }
         return true;
     }
 

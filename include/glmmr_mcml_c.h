@@ -193,9 +193,10 @@ typedef struct glmmr_mcml_ext {
     int      chains;    /* <= 1: the reference's single sequential chain; C: C concurrent chains */
     int      maxfun;    /* objective evaluations per optimiser call; 0 = 10000 (minqa default) */
     int      device;    /* HIP device ordinal */
-    int      theta_batch; /* candidate thetas per rank and round of the theta-step.  0: a sharded job (world > 1) runs
-                             the batch schedule with one candidate per rank and round, a single process the reference's
-                             sequential BOBYQA; k >= 2 forces the batch schedule with world * k candidates per round */
+    int      theta_batch; /* candidate thetas per rank and round of the theta-step's batch schedule (csrc/optim.h
+                             bobyqa_batch).  0 = default: 8 (2 per rank of a sharded job) when D consists of large dense
+                             blocks only -- a round's candidates are then factorised side by side in one pass -- else 1;
+                             1 = the reference's sequential BOBYQA (in a sharded job: one candidate per rank and round) */
 } glmmr_mcml_ext;
 
 /* gen_u_samples(y, X, Z, L, beta, family, sigma, warmup_iter, m) -> Q x m      -- R/gen_u_samples.R:38-69

@@ -200,25 +200,32 @@ def test_graph_replay_of_the_factorisation_is_bit_identical_to_eager_launches():
 
 @pytest.mark.parametrize("n,m", [(2000, 256), (5000, 1024)])
 def test_whole_mcml_iterations_theta_step_on_the_graph_equals_eager_evaluation(n, m, tmp_path):
-    """BASELINE configs 2 and 3 at full size, two whole mcml_full iterations (sampler -> MCNR -> 40-evaluation theta-step
-    on the replayed graph with the m sample columns appended -> L refresh; src/mcml_full.cpp:83-140): every objective
-    value the last theta-step saw is re-evaluated on the same samples by EAGER launches (GLMMR_MCML_CHOL_GRAPH=0, a
-    fresh process) and must agree to the last bit (mcmldmatrix.h:23-41); the fit stays in a band round the generating
-    values (theta = (0.25, 0.1), sigma = 1, beta = 1)."""
+    """BASELINE configs 2 and 3 at full size, two whole mcml_full iterations (sampler -> MCNR -> theta-step of at most 40
+    evaluations, eight candidates per round factorised side by side on the replayed graph with the m sample columns
+    appended -> L refresh; src/mcml_full.cpp:83-140): every objective value the last theta-step saw is re-evaluated on
+    the same samples ONE AT A TIME by EAGER launches (GLMMR_MCML_CHOL_GRAPH=0, a fresh process) and must agree to the
+    last bit (mcmldmatrix.h:23-41); the fit stays in a band round the generating values (theta = (0.25, 0.1), sigma = 1,
+    beta = 1)."""
     import json, os, subprocess, sys
     from glmmrmcml_amd import api
     d = synth.geospatial(n, seed=20240601)
+    kw = dict(mcnr=True, m=m, warmup=100, tol=0.0, lambda_=5.0, maxsteps=10, target_accept=0.9, seed=20240601, chains=m,
+              maxfun=40)
     with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"]) as ctx:
         ctx.theta_log(enable=True)
-        r = ctx.mcml_full(d["start"], mcnr=True, m=m, maxiter=2, warmup=100, tol=0.0, lambda_=5.0, maxsteps=10,
-                          target_accept=0.9, seed=20240601, chains=m, maxfun=40)
+        ctx.mcml_full(d["start"], maxiter=1, **kw)
+        n1 = ctx.theta_log(enable=True).shape[0]         # evaluations of the first theta-step (the same in the run below)
+        r = ctx.mcml_full(d["start"], maxiter=2, **kw)
         log = ctx.theta_log(enable=False)
         u = ctx.get_u()
+        sh = ctx.shard_stats()
     assert r["iters"] == 2 and u.shape == (n, m) and np.all(np.isfinite(u))
-    assert log.shape == (80, 3)                          # 40 evaluations per theta-step
-    last = log[40:]
+    assert 8 <= n1 <= 40 and n1 < log.shape[0] <= 80 and log.shape[1] == 3     # at most 40 evaluations per theta-step
+    # (a candidate at which D is not numerically positive definite is counted but has no value to log)
+    assert n1 + log.shape[0] <= sh["theta_evals_all"] <= n1 + log.shape[0] + 12 and sh["theta_rounds"] <= 3 * 7
+    last = log[n1:]
     assert 0.1 < r["theta"][0] < 0.6 and 0.03 < r["theta"][1] < 0.3 and 0.7 < r["sigma"] < 1.3 and 0.0 < r["beta"][0] < 2.0
-    assert np.all(np.isfinite(last)) and last[:, 2].max() >= log[:40, 2].max() - 50.0
+    assert np.all(np.isfinite(last))
     np.save(tmp_path / "u.npy", u); np.save(tmp_path / "th.npy", last[:, :2])
     code = ("import json, numpy as np\n"
             "from glmmrmcml_amd import api, synth\n"

@@ -215,3 +215,19 @@ def test_batch_objective_failure_and_nan():
     assert np.abs(x - [1, 0]).max() < 1e-5
     x, f, nf, rounds, _ = _bobyqa_batch(lambda x: float(np.sum(x ** 2)), [2.0, -1.0], 4, maxfun=3)
     assert nf <= 4 and np.isfinite(f)
+
+
+def test_batch_schedule_survives_points_without_a_value():
+    """a candidate at which the objective has no value (+inf / NaN: D(theta) not positive definite there) is 'worse than
+    anything seen', not an infinity inside the interpolation model: the run still converges to the sequential optimum"""
+    f = _mvn_objective()
+
+    def g(z):
+        th = np.exp(z)
+        return np.inf if th[1] > 0.12 else f(th)         # the first step along theta_2 of the initial design fails
+    ref = _bobyqa(f, [0.25, 0.1], lower=[1e-6] * 2, upper=[np.inf] * 2)
+    assert ref[0][1] < 0.12
+    for width in (4, 8):
+        z, fb, nf, rounds, _ = _bobyqa_batch(g, np.log([0.25, 0.1]), width, lower=[np.log(1e-6)] * 2, upper=[np.inf] * 2,
+                                             rhobeg=0.25, rhoend=1e-7)
+        assert abs(fb - ref[1]) < 1e-9 * abs(ref[1]) and np.abs(np.exp(z) - ref[0]).max() < 2e-6, (width, np.exp(z), ref[0])

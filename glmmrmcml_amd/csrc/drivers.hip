@@ -154,13 +154,14 @@ struct McmlOptim {
         const int wr = comm_world(c);
         // candidates per rank and round.  A model whose D is large dense blocks only (the geospatial configs) evaluates
         // a round's candidates in ONE pass of the factorisation's schedule (mvn.hip mvn_loglik_batch): there the batch
-        // schedule is the default even for a single process -- 8 candidates per round, 2 per rank of a sharded job
+        // schedule is the default even for a single process, 8 candidates per round; a rank of a sharded job keeps one
+        // candidate per round (measured at 8 ranks: rounds of 16 are rarely full, 202 against 191 ms per rank step)
         // (GLMMR_MCML_THETA_BATCH overrides, 1 = the reference's sequential BOBYQA).  glmmr_mcml_ext.theta_batch wins.
         int k = theta_batch;
         if (k <= 0) {
             static const int envk = getenv("GLMMR_MCML_THETA_BATCH") ? atoi(getenv("GLMMR_MCML_THETA_BATCH")) : 0;
             const bool dense_only = c.maxdim_large > 0 && c.n_small == 0 && c.n_diag_rows == 0;
-            k = envk > 0 ? envk : dense_only ? (wr > 1 ? 2 : 8) : 1;
+            k = envk > 0 ? envk : (dense_only && wr == 1) ? 8 : 1;
         }
         if ((wr > 1 && shard) || k > 1) return d_optim_sharded(wr * std::max(1, k));
         objective_fn f = [&](const std::vector<double>& par, double* v) {

@@ -194,8 +194,8 @@ typedef struct glmmr_mcml_ext {
     int      maxfun;    /* objective evaluations per optimiser call; 0 = 10000 (minqa default) */
     int      device;    /* HIP device ordinal */
     int      theta_batch; /* candidate thetas per rank and round of the theta-step's batch schedule (csrc/optim.h
-                             bobyqa_batch).  0 = default: 8 (2 per rank of a sharded job) when D consists of large dense
-                             blocks only -- a round's candidates are then factorised side by side in one pass -- else 1;
+                             bobyqa_batch).  0 = default: 8 for a single process whose D consists of large dense blocks
+                             only -- a round's candidates are then factorised side by side in one pass -- else 1;
                              1 = the reference's sequential BOBYQA (in a sharded job: one candidate per rank and round) */
 } glmmr_mcml_ext;
 

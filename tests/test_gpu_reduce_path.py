@@ -130,8 +130,7 @@ def test_world2_contexts_equal_one_context_with_all_chains(gen, gkw, mcnr):
     assert calls[0].count(gather) == 2 and sh["gathers"] == 2 and sh["gather_doubles"] == 2 * gather
     assert sh["theta_rounds"] >= 2 * 3 and sh["theta_evals_own"] + out[1]["shard"]["theta_evals_own"] == sh["theta_evals_all"]
     assert abs(sh["theta_evals_own"] - out[1]["shard"]["theta_evals_own"]) <= sh["theta_rounds"]
-    width = 2 * (2 if gen is synth.geospatial else 1)    # candidates per round: per rank 2 (one dense block: factorised
-    #                                                      side by side) or 1
+    width = 2                                            # candidates per round: one per rank
     assert sh["theta_evals_all"] <= width * sh["theta_rounds"]
     small = [n for n in calls[0] if n != gather]
     if mcnr:
@@ -145,8 +144,7 @@ def test_world2_contexts_equal_one_context_with_all_chains(gen, gkw, mcnr):
 def test_emulated_rank_record_and_replay():
     """glmmr_mcml_dbg_emulate_world: one rank of an 8-rank job whose peers are copies of itself.  Record (all candidate
     thetas evaluated here) and replay (rank 0's share only, the rest from the record) must give the same fit, and the
-    replay must evaluate rank 0's share (two of the sixteen candidates of a round: the model's D is one dense block,
-    whose default is two candidates per rank, factorised side by side)."""
+    replay must evaluate rank 0's share, one candidate per round."""
     from glmmrmcml_amd import api
     d = synth.geospatial(n=150, seed=9)
     args = (d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"])
@@ -168,8 +166,8 @@ def test_emulated_rank_record_and_replay():
     assert rec["sigma"] == rep["sigma"] and np.array_equal(urec, urep)
     assert urec.shape == (d["Q"], 64) and np.array_equal(urec[:, :8], urec[:, 56:])     # eight copies of the block
     rounds = s1["theta_rounds"]
-    assert rounds <= s1["theta_evals_own"] <= 2 * rounds                 # rank 0 owns slots 0 and 8 of a round of 16
-    assert s1["theta_evals_all"] <= 2 * 40 and s1["theta_evals_all"] > 4 * rounds       # rounds (of 16) are mostly full
+    assert s1["theta_evals_own"] == rounds                               # rank 0 owns slot 0 of a round of 8
+    assert s1["theta_evals_all"] <= 2 * 40 and s1["theta_evals_all"] > 4 * rounds       # rounds (of 8) are mostly full
     assert s2["theta_rounds"] - rounds == rounds and s2["theta_evals_own"] - s1["theta_evals_own"] == s1["theta_evals_own"]
 
 

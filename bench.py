@@ -308,13 +308,15 @@ def main():
         # separate rocprofv3 --pmc run of this same command (scripts/pmc_traffic.py writes the json); quoted
         # only when it was taken on this workload, with the file it came from
         traffic = None; traffic_src = None
-        pj = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+        pj = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+        if not os.path.exists(pj):
+            pj = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
         if os.path.exists(pj):
             try:
                 tj = json.load(open(pj))
                 if tj.get("n") == n and tj.get("chains") == C and bool(tj.get("dense_z")) == bool(args.dense_z):
                     traffic = tj.get("hbm_bytes_per_launch_%s" % prof["operator"])
-                    traffic_src = "profiles/r02_hbm_traffic.json (%s)" % tj.get("build", "?")
+                    traffic_src = "profiles/%s (%s)" % (os.path.basename(pj), tj.get("build", "?"))
             except Exception:
                 traffic = None
         line = {

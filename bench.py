@@ -266,6 +266,9 @@ def main():
         # recording run: the very iterations that are timed below, every rank's candidate thetas evaluated here
         ctx.emulate_world(emu, 1)
         run(args.steps)
+        # replay once untimed (first use of the single-candidate path: workspace, graph capture), then again timed
+        ctx.emulate_world(emu, 2)
+        run(args.steps)
         ctx.emulate_world(emu, 2)
     elif args.warmup > 0:
         run(args.warmup)

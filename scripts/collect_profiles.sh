@@ -9,16 +9,16 @@ PY=python3
 # 1. the bench line itself (no profiler) + kernel stats of the same command
 $PY bench.py --steps 5 --warmup 2 > $O/bench_line.json 2> $O/bench_line.err
 echo "bench line done" 
-rocprofv3 --kernel-trace -d $O/kt_bench -o b -- $PY bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/kt_bench.log 2>&1
+rocprofv3 --kernel-trace -d $O/kt_bench -o b -- $PY bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $O/kt_bench.log 2>&1
 $PY scripts/rocpd_stats.py $O/kt_bench/b_results.db > $O/bench_kernel_stats.csv
 echo "bench kernel trace done"
 # 2. SQ counters on the shipping kernels
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/sq -o sq -- $PY bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/sq.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/sq -o sq -- $PY bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs > $O/sq.log 2>&1
 $PY scripts/pmc_summary.py $O/sq/sq_counter_collection.csv dgemm_band k_band_reduce dgemm_dl_kernel k_potrf_leaf > $O/bench_sq_counters.csv
 echo "sq done"
 # 3. HBM traffic
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/f -o f -- $PY bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/w -o w -- $PY bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/f -o f -- $PY bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs > $O/f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/w -o w -- $PY bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs > $O/w.log 2>&1
 $PY scripts/make_traffic_json.py $O/f $O/w 5000 1024 0 "$BUILD" > $O/hbm_traffic.json
 echo "traffic done"
 # 4. one rank of the 8-GPU job (128 chains, its share of every theta-step round; peers emulated), the same with the

@@ -30,6 +30,7 @@ struct HmcState {
     int partial_slots = 0;
     bool cm = false;            // chain-major state (sparse ZL operator, hmc_cm.h): element (c, r) at c + r * ld
     DevBuf cm_part, cm_acc;     // chain-major path: partial sums (ll | lp | kin | ss), accept flags
+    DevBuf cm_part_fwd;         // ... and the log-density partials the last forward product of a trajectory leaves (one per workgroup)
     DevMat LX, ZS;              // factored operator (SparseZL::factored): L X and Z' S, C x Q
 };
 

@@ -482,7 +482,9 @@ static int hmc_forward_launch(Ctx& c, const double* X, int ldx, const Epi& epi)
     return launch_gemm<false>(c.stream, c.n, h.Cw, c.Q, c.ZL.d(), c.ZL.ld, X, ldx, epi);
 }
 
-static int hmc_forward(Ctx& c, const double* X, int ldx, double var_par, bool store_mu = true, bool chain = false)
+// want_ll (sparse operator only): leave the per-chain partial sums of log f(y | MU) in h.cm_part_fwd instead of MU
+static int hmc_forward(Ctx& c, const double* X, int ldx, double var_par, bool store_mu = true, bool chain = false,
+                       bool want_ll = false)
 {
     HmcState& h = c.hmc;
     const int slot = c.prof.begin(c.stream, 0, chain);
@@ -498,8 +500,13 @@ static int hmc_forward(Ctx& c, const double* X, int ldx, double var_par, bool st
                                c.sp.row_start.as<int>(), c.L.d(), c.L.ld, X, h.LX.d());
             W = c.z_width; col = c.z_idx.as<int>(); val = c.z_val.d(); Xin = h.LX.d();
         }
+        double* pll = nullptr;
+        if (want_ll) {
+            MCML_TRY(h.cm_part_fwd.ensure(sizeof(double) * (size_t)grid.x * h.V.ld));
+            pll = h.cm_part_fwd.d();
+        }
 #define MCML_CMF(FL) hipLaunchKernelGGL((k_cm_forward<FL>), grid, dim3(256), 0, c.stream, c.n, h.Cw, h.V.ld, W, col, val, Xin, \
-                                        c.xb.d(), c.y.d(), c.flink, var_par, store_mu ? 1 : 0, h.MU.d(), h.S.d(), rpw)
+                                        c.xb.d(), c.y.d(), c.flink, var_par, store_mu ? 1 : 0, h.MU.d(), h.S.d(), rpw, pll, h.V.ld)
         switch (c.flink) {
         case 1: MCML_CMF(1); break;
         case 3: MCML_CMF(3); break;
@@ -582,6 +589,7 @@ static CmChain cm_chain(const ChainArrays& a)
 {
     return CmChain{a.e, a.ebar, a.H, a.lpcur, a.K0, a.steps, a.acc, a.gen, a.leap};
 }
+static int cm_fwd_chunks(const Ctx& c) { return (c.n + 4 * CM_FR - 1) / (4 * CM_FR); }     // workgroups of k_cm_forward = its ll partials
 struct CmParts { double *ll, *lp, *kin, *ss; int nchn, nchq, ldp; };
 static CmParts cm_parts(const Ctx& c)
 {
@@ -593,13 +601,15 @@ static CmParts cm_parts(const Ctx& c)
     return p;
 }
 // partial sums of log f(y | MU) + log N(X; 0, 1) (+ R^2) of every chain
-static int cm_logprob_partials(Ctx& c, const double* X, const double* R, double var_par)
+// skip_ll: the observation part came out of the last forward product (hmc_forward want_ll); only the prior / kinetic part runs
+static int cm_logprob_partials(Ctx& c, const double* X, const double* R, double var_par, bool skip_ll = false)
 {
     HmcState& h = c.hmc;
     const CmParts p = cm_parts(c);
-    const dim3 grid((h.Cw + 63) / 64, p.nchn + p.nchq);
+    const int nchn = skip_ll ? 0 : p.nchn;
+    const dim3 grid((h.Cw + 63) / 64, nchn + p.nchq);
 #define MCML_LP_LAUNCH(FL) hipLaunchKernelGGL((k_cm_logprob_partials<FL>), grid, dim3(256), 0, c.stream, h.MU.d(), X, R, h.V.ld, \
-                       c.n, c.Q, h.Cw, c.y.d(), var_par, c.flink, p.nchn, p.ll, p.lp, p.kin, p.ldp)
+                       c.n, c.Q, h.Cw, c.y.d(), var_par, c.flink, nchn, p.ll, p.lp, p.kin, p.ldp)
     switch (c.flink) {                       // the common families get their own instantiation
     case 1: MCML_LP_LAUNCH(1); break;        // poisson / log
     case 3: MCML_LP_LAUNCH(3); break;        // binomial / logit
@@ -616,12 +626,12 @@ static int hmc_eval_state(Ctx& c, double var_par)
 {
     HmcState& h = c.hmc;
     ChainArrays ca = chain_arrays(h);
-    MCML_TRY(hmc_forward(c, h.V.d(), h.V.ld, var_par));
+    MCML_TRY(hmc_forward(c, h.V.d(), h.V.ld, var_par, !h.cm, false, h.cm));
     if (h.cm) {
         const CmParts p = cm_parts(c);
-        MCML_TRY(cm_logprob_partials(c, h.V.d(), nullptr, var_par));
-        hipLaunchKernelGGL(k_cm_lp0_fin, dim3((h.C + 63) / 64), dim3(256), 0, c.stream, p.ll, p.lp, p.nchn, p.nchq, p.ldp,
-                           h.C, ca.lpcur);
+        MCML_TRY(cm_logprob_partials(c, h.V.d(), nullptr, var_par, true));
+        hipLaunchKernelGGL(k_cm_lp0_fin, dim3((h.C + 63) / 64), dim3(256), 0, c.stream, h.cm_part_fwd.d(), p.lp, cm_fwd_chunks(c),
+                           p.nchq, p.ldp, h.C, ca.lpcur);
     } else
     MCML_FL_DISPATCH(c.flink, k_hmc_lp0, dim3(h.C), dim3(256), 0, c.stream, h.MU.d(), h.MU.ld, c.n, h.V.d(), h.V.ld, c.Q,
                        c.y.d(), var_par, c.flink, ca.lpcur);
@@ -703,12 +713,14 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         ~RingGuard() { (void)hipStreamSynchronize(s); for (int i = 0; i < n; ++i) (void)hipEventDestroy(ev[i]); (void)hipHostFree(p); }
     } ring_guard{h_ring, ring_ev, RING, c.stream};
     int seen_maxs = -1;                         // latest step count actually observed
+    bool pending_commit = false;                // sparse operator: the last decisions are applied by the next k_cm_propose
     for (int it = 0; it < total; ++it) {
         if (h.cm) {
             const CmParts p = cm_parts(c);
             hipLaunchKernelGGL(k_cm_propose, dim3((C + 63) / 64, p.nchq), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(),
                                h.UP.d(), h.V.ld, Q, C, cm_chain(ca), seed, (uint32_t)o->chain_offset, iter_idx, it, p_mom,
-                               p.ss, p.ldp);
+                               p.ss, p.ldp, pending_commit ? h.cm_acc.as<int>() : nullptr, h.GRADP.d());
+            pending_commit = false;
             hipLaunchKernelGGL(k_cm_propose_fin, dim3((C + 63) / 64), dim3(256), 0, c.stream, p.ss, p.nchq, p.ldp, C,
                                cm_chain(ca), o->lambda, o->max_steps);
         } else
@@ -739,7 +751,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         c.prof.skip = (it & 3) != 0;
         int rc_traj = MCML_OK;
         for (int s = 0; s < maxs && rc_traj == MCML_OK; ++s) {
-            rc_traj = hmc_forward(c, h.UP.d(), h.UP.ld, var_par, s == maxs - 1, s > 0);
+            rc_traj = hmc_forward(c, h.UP.d(), h.UP.ld, var_par, !h.cm && s == maxs - 1, s > 0, h.cm && s == maxs - 1);
             if (rc_traj == MCML_OK) rc_traj = hmc_backward(c, h.UP.d(), h.GRADP.d(), s, var_par, 1, true);
         }
         c.prof.skip = false;
@@ -748,13 +760,17 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         const int adapt = (it < o->warmup) && (it < o->adapt);     // mhmcmc.h:131-136
         if (h.cm) {
             const CmParts p = cm_parts(c);
-            MCML_TRY(cm_logprob_partials(c, h.UP.d(), h.R.d(), var_par));
-            hipLaunchKernelGGL(k_cm_accept_fin, dim3((C + 63) / 64), dim3(256), 0, c.stream, p.ll, p.lp, p.kin, p.nchn, p.nchq,
-                               p.ldp, C, cm_chain(ca), o->target_accept, adapt, it,
+            MCML_TRY(cm_logprob_partials(c, h.UP.d(), h.R.d(), var_par, true));
+            hipLaunchKernelGGL(k_cm_accept_fin, dim3((C + 63) / 64), dim3(256), 0, c.stream, h.cm_part_fwd.d(), p.lp, p.kin,
+                               cm_fwd_chunks(c), p.nchq, p.ldp, C, cm_chain(ca), o->target_accept, adapt, it,
                                flags_out ? d_flags.as<uint8_t>() : nullptr, probs_out ? d_probs.d() : nullptr,
                                h.cm_acc.as<int>());
-            hipLaunchKernelGGL(k_cm_commit, dim3((C + 63) / 64, p.nchq), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.UP.d(),
-                               h.GRADP.d(), h.V.ld, Q, C, h.cm_acc.as<int>());
+            // the accepted chains' V <- UP, GRAD <- GRADP: folded into the next proposal's first pass unless V is read
+            // before that (a draw is stored after this proposal, or it is the last one)
+            const bool stores_now = (C == 1) ? (it >= o->warmup - 1) : (it >= o->warmup);
+            if (it + 1 < total && !stores_now) pending_commit = true;
+            else hipLaunchKernelGGL(k_cm_commit, dim3((C + 63) / 64, p.nchq), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.UP.d(),
+                                    h.GRADP.d(), h.V.ld, Q, C, h.cm_acc.as<int>());
         } else
         MCML_FL_DISPATCH(c.flink, k_hmc_accept, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(), h.UP.d(),
                            h.GRADP.d(), h.V.ld, Q, h.MU.d(), h.MU.ld, n, c.y.d(), var_par, c.flink, ca,

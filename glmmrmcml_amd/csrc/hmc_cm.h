@@ -63,16 +63,22 @@ __device__ __forceinline__ void sload_f64x2(const double* a, const double* b, do
 // a wave owns CM_FR consecutive observations: the k loop is outermost so that CM_FR independent gathers are in
 // flight per iteration, then CM_FR independent scores and stores
 constexpr int CM_FR = 4;       // 8 measured slower (152 vs 121 us at config 5)
+// part_ll (nullable): the workgroup's 16 observations' log f(y_i | MU[c, i]) summed per chain -- rows in order inside a wave,
+// the four waves in wave order through LDS -- at part_ll[blockIdx.x * ldp + c].  On the last step of a trajectory the
+// accept kernel needs exactly that sum: taking it here saves the store of MU (n x C) and the pass that read it back
+// (k_cm_logprob_partials: 173 us per proposal at config 5).
 template <int FL>      // family / link code at compile time (12 = beta/logit), 0 = run-time code (EpiForwardT, hmc.hip)
 __global__ __launch_bounds__(256) void k_cm_forward(int n, int C, int ldc, int W, const int* col, const double* val,
                                                     const double* X, const double* xb, const double* y, int flink,
-                                                    double var_par, int store_mu, double* MU, double* S, int rpw)
+                                                    double var_par, int store_mu, double* MU, double* S, int rpw,
+                                                    double* part_ll, int ldp)
 {
     (void)rpw;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.y * 64 + lane;
     const int i0 = (blockIdx.x * 4 + w) * CM_FR;
-    if (c >= C || i0 >= n) return;
+    double llsum = 0.0;
+    if (c < C && i0 < n) {
     double acc[CM_FR];
 #pragma unroll
     for (int r = 0; r < CM_FR; ++r) acc[r] = 0.0;
@@ -126,7 +132,15 @@ __global__ __launch_bounds__(256) void k_cm_forward(int n, int C, int ldc, int W
             if (store_mu) MU[off] = mu;
             if constexpr (FL == 12) S[off] = glm_score_beta(yi, mu, var_par);
             else S[off] = glm_score(yi, mu, FL ? FL : flink);
+            if (part_ll) llsum += glm_logpdf(yi, mu, var_par, FL ? FL : flink);
         }
+    }
+    }
+    if (part_ll) {                                    // uniform: every wave of the workgroup gets here
+        __shared__ double sh[4][64];
+        sh[w][lane] = llsum;
+        __syncthreads();
+        if (w == 0 && c < C) part_ll[(size_t)blockIdx.x * ldp + c] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
     }
 }
 
@@ -402,11 +416,14 @@ __global__ __launch_bounds__(256) void k_cm_lp0_fin(const double* part_ll, const
     lpcur[c] = a + b;                                             // ll.sum() + lp.sum(), mcmlmodel.h:151
 }
 
-// new_proposal, first part (mhmcmc.h:62-75): momentum, first half step + position; partial sums of r^2
-__global__ __launch_bounds__(256) void k_cm_propose(const double* V, const double* GRAD, double* R, double* UP, int ldc,
+// new_proposal, first part (mhmcmc.h:62-75): momentum, first half step + position; partial sums of r^2.
+// accflag (nullable): the PREVIOUS proposal's decisions, not yet applied to V / GRAD -- an accepted chain's state is read
+// from UP / GRADP and written through to V / GRAD here, so the separate commit pass (k_cm_commit: one more read and write of
+// the Q x C state, 131 us per proposal at config 5) is folded into this one.
+__global__ __launch_bounds__(256) void k_cm_propose(double* V, double* GRAD, double* R, double* UP, int ldc,
                                                     int Q, int C, CmChain ca, uint64_t seed, uint32_t chain_offset,
                                                     uint32_t iter_idx, int it, const double* inj_mom, double* part_ss,
-                                                    int ldp)
+                                                    int ldp, const int* accflag, const double* GRADP)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -422,7 +439,9 @@ __global__ __launch_bounds__(256) void k_cm_propose(const double* V, const doubl
             double r = inj_mom ? inj_mom[q + ((size_t)it * C + c) * Q]
                                : rng_normal(seed, (uint32_t)q, gid, (uint32_t)it, 16u * iter_idx + 2u);
             ss += r * r;
-            const double g = GRAD[off], v = V[off];
+            double g, v;
+            if (accflag && accflag[c]) { g = GRADP[off]; v = UP[off]; GRAD[off] = g; V[off] = v; }
+            else { g = GRAD[off]; v = V[off]; }
             r = r + (e / 2) * g;
             R[off] = r;
             UP[off] = v + e * r;

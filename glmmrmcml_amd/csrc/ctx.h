@@ -116,6 +116,25 @@ struct CholGraph {
     hipGraphExec_t exec = nullptr;
     const double* A = nullptr; const double* linv = nullptr; int lda = 0, n = 0, extra = 0, seen = 0;
     long long used = 0;                 // launch counter value at the last use (the least recently used entry is replaced)
+    // Calibration (mvn.hip potrf_graphed).  On this stack every other hipGraphInstantiate in a process yields an
+    // executable whose two chains run 1.5-2x slower than the same graph instantiated before or after it (measured: the
+    // 3rd and 5th instantiation; the parallel branch lands on a hardware queue that does not overlap with the launch
+    // stream's).  The first replays are therefore timed against the eager launch sequence and a slow executable is
+    // instantiated again from the kept template.
+    hipGraph_t tmpl = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    float eager_ms = 0.f, best_ms = 0.f;
+    hipGraphExec_t best = nullptr;      // fastest executable seen so far while `exec` is the one on trial
+    int tries = 0, trial_launches = 0;  // an executable's first launch carries its upload: the second one is timed
+    bool timed = false, settled = false, branchy = false;
+    void release() {
+        if (best && best != exec) (void)hipGraphExecDestroy(best);
+        best = nullptr;
+        if (exec) { (void)hipGraphExecDestroy(exec); exec = nullptr; }
+        if (tmpl) { (void)hipGraphDestroy(tmpl); tmpl = nullptr; }
+        if (t0) { (void)hipEventDestroy(t0); t0 = nullptr; }
+        if (t1) { (void)hipEventDestroy(t1); t1 = nullptr; }
+    }
 };
 // a few graphs side by side: a model with two or more large covariance blocks of different size evaluates them in turn,
 // and a one-entry cache would re-capture (i.e. run eagerly) every time
@@ -123,27 +142,30 @@ struct CholGraphCache {
     static constexpr int CAP = 4;
     std::vector<CholGraph> g;
     long long tick = 0;
-    void clear() { for (CholGraph& e : g) if (e.exec) (void)hipGraphExecDestroy(e.exec); g.clear(); }
+    void clear() { for (CholGraph& e : g) e.release(); g.clear(); }
     ~CholGraphCache() { clear(); }
     CholGraphCache() = default;
     CholGraphCache(const CholGraphCache&) = delete;
     CholGraphCache& operator=(const CholGraphCache&) = delete;
     CholGraphCache(CholGraphCache&& o) noexcept : g(std::move(o.g)), tick(o.tick) { o.g.clear(); }
     CholGraphCache& operator=(CholGraphCache&& o) noexcept { if (this != &o) { clear(); g = std::move(o.g); tick = o.tick; o.g.clear(); } return *this; }
-    CholGraph& find(const double* A, const double* linv, int lda, int n, int extra) {
+    // branchy: a two-chain graph (a single evaluation) -- at most two of those are kept alive (of three or more alive in
+    // a process every new instantiation measured slow, whatever the number of tries); one-chain graphs (batches): four
+    CholGraph& find(const double* A, const double* linv, int lda, int n, int extra, bool branchy) {
         ++tick;
         for (CholGraph& e : g)
             if (e.A == A && e.linv == linv && e.lda == lda && e.n == n && e.extra == extra) { e.used = tick; return e; }
-        if ((int)g.size() < CAP) g.push_back(CholGraph());
-        else {
-            size_t old = 0;
-            for (size_t i = 1; i < g.size(); ++i) if (g[i].used < g[old].used) old = i;
-            if (g[old].exec) (void)hipGraphExecDestroy(g[old].exec);
+        const int cap = branchy ? 2 : CAP;
+        int have = 0; size_t old = g.size();
+        for (size_t i = 0; i < g.size(); ++i)
+            if (g[i].branchy == branchy) { ++have; if (old == g.size() || g[i].used < g[old].used) old = i; }
+        if (have >= cap) {
+            g[old].release();
             g[old] = CholGraph();
             std::swap(g[old], g.back());
-        }
+        } else g.push_back(CholGraph());
         CholGraph& e = g.back();
-        e.A = A; e.linv = linv; e.lda = lda; e.n = n; e.extra = extra; e.seen = 0; e.used = tick;
+        e.A = A; e.linv = linv; e.lda = lda; e.n = n; e.extra = extra; e.seen = 0; e.used = tick; e.branchy = branchy;
         return e;
     }
 };

@@ -590,6 +590,12 @@ static CmChain cm_chain(const ChainArrays& a)
     return CmChain{a.e, a.ebar, a.H, a.lpcur, a.K0, a.steps, a.acc, a.gen, a.leap};
 }
 static int cm_fwd_chunks(const Ctx& c) { return (c.n + 4 * CM_FR - 1) / (4 * CM_FR); }     // workgroups of k_cm_forward = its ll partials
+// GLMMR_MCML_CM_FUSE=0: the round-2 sequence (MU stored and read back by k_cm_logprob_partials, separate k_cm_commit): the A/B switch
+static bool cm_fuse()
+{
+    static const bool v = !(getenv("GLMMR_MCML_CM_FUSE") && !strcmp(getenv("GLMMR_MCML_CM_FUSE"), "0"));
+    return v;
+}
 struct CmParts { double *ll, *lp, *kin, *ss; int nchn, nchq, ldp; };
 static CmParts cm_parts(const Ctx& c)
 {
@@ -626,12 +632,13 @@ static int hmc_eval_state(Ctx& c, double var_par)
 {
     HmcState& h = c.hmc;
     ChainArrays ca = chain_arrays(h);
-    MCML_TRY(hmc_forward(c, h.V.d(), h.V.ld, var_par, !h.cm, false, h.cm));
+    const bool fuse = h.cm && cm_fuse();
+    MCML_TRY(hmc_forward(c, h.V.d(), h.V.ld, var_par, !fuse, false, fuse));
     if (h.cm) {
         const CmParts p = cm_parts(c);
-        MCML_TRY(cm_logprob_partials(c, h.V.d(), nullptr, var_par, true));
-        hipLaunchKernelGGL(k_cm_lp0_fin, dim3((h.C + 63) / 64), dim3(256), 0, c.stream, h.cm_part_fwd.d(), p.lp, cm_fwd_chunks(c),
-                           p.nchq, p.ldp, h.C, ca.lpcur);
+        MCML_TRY(cm_logprob_partials(c, h.V.d(), nullptr, var_par, fuse));
+        hipLaunchKernelGGL(k_cm_lp0_fin, dim3((h.C + 63) / 64), dim3(256), 0, c.stream, fuse ? h.cm_part_fwd.d() : p.ll, p.lp,
+                           fuse ? cm_fwd_chunks(c) : p.nchn, p.nchq, p.ldp, h.C, ca.lpcur);
     } else
     MCML_FL_DISPATCH(c.flink, k_hmc_lp0, dim3(h.C), dim3(256), 0, c.stream, h.MU.d(), h.MU.ld, c.n, h.V.d(), h.V.ld, c.Q,
                        c.y.d(), var_par, c.flink, ca.lpcur);
@@ -751,7 +758,8 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         c.prof.skip = (it & 3) != 0;
         int rc_traj = MCML_OK;
         for (int s = 0; s < maxs && rc_traj == MCML_OK; ++s) {
-            rc_traj = hmc_forward(c, h.UP.d(), h.UP.ld, var_par, !h.cm && s == maxs - 1, s > 0, h.cm && s == maxs - 1);
+            const bool fuse = h.cm && cm_fuse();
+            rc_traj = hmc_forward(c, h.UP.d(), h.UP.ld, var_par, !fuse && s == maxs - 1, s > 0, fuse && s == maxs - 1);
             if (rc_traj == MCML_OK) rc_traj = hmc_backward(c, h.UP.d(), h.GRADP.d(), s, var_par, 1, true);
         }
         c.prof.skip = false;
@@ -760,15 +768,16 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         const int adapt = (it < o->warmup) && (it < o->adapt);     // mhmcmc.h:131-136
         if (h.cm) {
             const CmParts p = cm_parts(c);
-            MCML_TRY(cm_logprob_partials(c, h.UP.d(), h.R.d(), var_par, true));
-            hipLaunchKernelGGL(k_cm_accept_fin, dim3((C + 63) / 64), dim3(256), 0, c.stream, h.cm_part_fwd.d(), p.lp, p.kin,
-                               cm_fwd_chunks(c), p.nchq, p.ldp, C, cm_chain(ca), o->target_accept, adapt, it,
+            const bool fuse = cm_fuse();
+            MCML_TRY(cm_logprob_partials(c, h.UP.d(), h.R.d(), var_par, fuse));
+            hipLaunchKernelGGL(k_cm_accept_fin, dim3((C + 63) / 64), dim3(256), 0, c.stream, fuse ? h.cm_part_fwd.d() : p.ll, p.lp, p.kin,
+                               fuse ? cm_fwd_chunks(c) : p.nchn, p.nchq, p.ldp, C, cm_chain(ca), o->target_accept, adapt, it,
                                flags_out ? d_flags.as<uint8_t>() : nullptr, probs_out ? d_probs.d() : nullptr,
                                h.cm_acc.as<int>());
             // the accepted chains' V <- UP, GRAD <- GRADP: folded into the next proposal's first pass unless V is read
             // before that (a draw is stored after this proposal, or it is the last one)
             const bool stores_now = (C == 1) ? (it >= o->warmup - 1) : (it >= o->warmup);
-            if (it + 1 < total && !stores_now) pending_commit = true;
+            if (fuse && it + 1 < total && !stores_now) pending_commit = true;
             else hipLaunchKernelGGL(k_cm_commit, dim3((C + 63) / 64, p.nchq), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.UP.d(),
                                     h.GRADP.d(), h.V.ld, Q, C, h.cm_acc.as<int>());
         } else

@@ -340,6 +340,32 @@ extern "C" int glmmr_mcml_dbg_bobyqa_batch(glmmr_mcml_objective f, void* user, i
     if (rounds_out) *rounds_out = r.rounds;
     return MCML_OK;
 }
+// the same with a BATCH callback: fb(X /* n x k, column-major */, n, k, F /* k values out */, user) evaluates a whole round --
+// what a rank of a sharded job does (its own candidates, then the exchange); tests/test_dist_gloo.py runs it over gloo
+extern "C" int glmmr_mcml_dbg_bobyqa_rounds(glmmr_mcml_batch_objective fb, void* user, int n, const double* x0,
+                                            const double* lower, const double* upper, double rhobeg, double rhoend,
+                                            int maxfun, int width, double* x_out, double* f_out, int* nfev_out,
+                                            int* rounds_out)
+{
+    MCML_REQUIRE(fb && n > 0 && x0 && x_out && width >= 1, "dbg_bobyqa_rounds: bad argument");
+    batch_objective_fn obj = [&](const std::vector<std::vector<double>>& X, std::vector<double>* F) {
+        const int k = (int)X.size();
+        std::vector<double> flat((size_t)n * k);
+        for (int j = 0; j < k; ++j) for (int i = 0; i < n; ++i) flat[(size_t)j * n + i] = X[j][i];
+        F->assign(k, 0.0);
+        return fb(flat.data(), n, k, F->data(), user); };
+    std::vector<double> x(x0, x0 + n), lo(n, -HUGE_VAL), up(n, HUGE_VAL);
+    if (lower) lo.assign(lower, lower + n);
+    if (upper) up.assign(upper, upper + n);
+    BobyqaOpts o; o.rhobeg = rhobeg; o.rhoend = rhoend; if (maxfun > 0) o.maxfun = maxfun;
+    BobyqaResult r;
+    MCML_TRY(bobyqa_batch(obj, x, lo, up, o, width, &r));
+    for (int i = 0; i < n; ++i) x_out[i] = r.x[i];
+    if (f_out) *f_out = r.fval;
+    if (nfev_out) *nfev_out = r.nfev;
+    if (rounds_out) *rounds_out = r.rounds;
+    return MCML_OK;
+}
 extern "C" int glmmr_mcml_dbg_fd_hessian(glmmr_mcml_objective f, void* user, int n, const double* x, double ndeps,
                                          int usebounds, const double* lower, const double* upper, double* H)
 {

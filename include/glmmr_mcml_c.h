@@ -358,6 +358,12 @@ int glmmr_mcml_dbg_bobyqa(glmmr_mcml_objective f, void* user, int n, const doubl
 int glmmr_mcml_dbg_bobyqa_batch(glmmr_mcml_objective f, void* user, int n, const double* x0, const double* lower,
                                 const double* upper, double rhobeg, double rhoend, int maxfun, int width,
                                 double* x_out, double* f_out, int* nfev_out, int* rounds_out);
+/* the same driven by a batch callback: one call per round with all its points (X is n x k column-major, F receives k values;
+ * returns 0 or an error code that aborts the run) -- the shape of a rank's work in a sharded theta-step */
+typedef int (*glmmr_mcml_batch_objective)(const double* X, int n, int k, double* F, void* user);
+int glmmr_mcml_dbg_bobyqa_rounds(glmmr_mcml_batch_objective fb, void* user, int n, const double* x0, const double* lower,
+                                 const double* upper, double rhobeg, double rhoend, int maxfun, int width,
+                                 double* x_out, double* f_out, int* nfev_out, int* rounds_out);
 int glmmr_mcml_dbg_fd_hessian(glmmr_mcml_objective f, void* user, int n, const double* x, double ndeps,
                               int usebounds, const double* lower, const double* upper, double* H);
 int glmmr_mcml_dbg_dgemm_bench(int M, int N, int K, int b_nmajor, int iters, int force_tile,

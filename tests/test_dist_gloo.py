@@ -87,3 +87,85 @@ def test_reduce_hook_wraps_a_device_pointer_without_copy():
     arr = gdist._DevArray(0x7f0000001000, 5)
     cai = arr.__cuda_array_interface__
     assert cai["shape"] == (5,) and cai["typestr"] == "<f8" and cai["data"] == (0x7f0000001000, False)
+
+
+# ---- the candidate-sharded theta-step (csrc/drivers.hip d_optim_sharded) over gloo ------------------------------------
+# The product's optimiser (bobyqa_batch, host code of the library) runs on BOTH ranks; a round's candidates are split
+# j mod world; every rank evaluates its share on ALL sample columns -- here with the CPU oracle's mvn_ll, after an
+# all_gather of the ranks' columns -- and one all-reduce of a vector that is zero outside the owner's slots carries the
+# values.  Under test: both ranks propose identical points in every round without any further agreement, the exchange
+# pattern (one gather, one small all-reduce per round), and that the result is the single-process optimum.
+def _theta_worker(rank, world, port, out):
+    import ctypes as C
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    from glmmrmcml_amd import _lib
+    from oracle import oracle as orc
+    d = synth.geospatial(40, seed=3)
+    rng = np.random.default_rng(100)                      # all columns, then this rank's share (what its sampler left)
+    D = orc.gen_D(d["cov"], d["data"], d["eff_range"], d["theta"])
+    U_all = np.linalg.cholesky(D) @ rng.standard_normal((40, 12))
+    lo, hi = gdist.shard(12, world, rank)
+    parts = [torch.zeros(40, 12 // world, dtype=torch.float64) for _ in range(world)]
+    tdist.all_gather(parts, torch.from_numpy(np.ascontiguousarray(U_all[:, lo:hi])))          # ONE gather per theta-step
+    U = np.concatenate([p.numpy() for p in parts], axis=1)
+    assert np.array_equal(U, U_all)
+    rounds = []
+
+    def fb(Xp, n, k, Fp, user):
+        X = np.array([[Xp[j * n + i] for i in range(n)] for j in range(k)])
+        vals = np.zeros(k)
+        for j in range(k):
+            if j % world == rank:
+                try:
+                    vals[j] = -orc.mvn_ll(d["cov"], d["data"], d["eff_range"], np.exp(X[j]), U)
+                except RuntimeError:
+                    vals[j] = np.inf
+        t = torch.from_numpy(vals)
+        tdist.all_reduce(t, op=tdist.ReduceOp.SUM)          # every slot is zero on all ranks but its owner
+        rounds.append((X.copy(), t.numpy().copy()))
+        for j in range(k):
+            Fp[j] = float(t[j])
+        return 0
+    dp = C.POINTER(C.c_double)
+    cb = C.CFUNCTYPE(C.c_int, dp, C.c_int, C.c_int, dp, C.c_void_p)(fb)
+    z0 = np.log(np.asarray(d["theta"], float) * np.array([1.3, 0.8])); lo_b = np.full(2, np.log(1e-6)); up_b = np.full(2, np.inf)
+    x = np.zeros(2); f = C.c_double(); nf = C.c_int(); rd = C.c_int()
+    _lib.check(_lib.lib().glmmr_mcml_dbg_bobyqa_rounds(cb, None, 2, z0.ctypes.data_as(dp), lo_b.ctypes.data_as(dp),
+                                                       up_b.ctypes.data_as(dp), C.c_double(0.25), C.c_double(1e-7), 0, world,
+                                                       x.ctypes.data_as(dp), C.byref(f), C.byref(nf), C.byref(rd)))
+    out[rank] = dict(theta=np.exp(x), f=f.value, nf=nf.value, rounds=rd.value,
+                     pts=[r[0] for r in rounds], vals=[r[1] for r in rounds])
+    tdist.destroy_process_group()
+
+
+def test_candidate_sharded_theta_step_over_gloo(orc):
+    import ctypes as C
+    from glmmrmcml_amd import _lib
+    world = 2
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_theta_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    # both ranks ran the same rounds on the same values and ended at the same point, with nothing exchanged but the values
+    assert a["rounds"] == b["rounds"] == len(a["pts"]) and a["nf"] == b["nf"]
+    assert all(np.array_equal(p, q) for p, q in zip(a["pts"], b["pts"])) and all(np.array_equal(p, q) for p, q in zip(a["vals"], b["vals"]))
+    assert np.array_equal(a["theta"], b["theta"]) and a["f"] == b["f"]
+    assert max(p.shape[0] for p in a["pts"]) <= world and a["rounds"] < a["nf"]
+    # ... which is the optimum the sequential optimiser finds on all columns in one process
+    d = synth.geospatial(40, seed=3)
+    D = orc.gen_D(d["cov"], d["data"], d["eff_range"], d["theta"])
+    U = np.linalg.cholesky(D) @ np.random.default_rng(100).standard_normal((40, 12))
+    dp = C.POINTER(C.c_double)
+
+    def obj(xp, n, user):
+        try:
+            return -orc.mvn_ll(d["cov"], d["data"], d["eff_range"], np.array([xp[0], xp[1]]), U)
+        except RuntimeError:
+            return 1e300
+    cb = C.CFUNCTYPE(C.c_double, dp, C.c_int, C.c_void_p)(obj)
+    x0 = np.asarray(d["theta"], float) * np.array([1.3, 0.8]); lo = np.full(2, 1e-6); up = np.full(2, np.inf)
+    x = np.zeros(2); f = C.c_double(); nf = C.c_int()
+    _lib.check(_lib.lib().glmmr_mcml_dbg_bobyqa(cb, None, 2, x0.ctypes.data_as(dp), lo.ctypes.data_as(dp), up.ctypes.data_as(dp),
+                                                C.c_double(0.0), C.c_double(1e-9), 0, x.ctypes.data_as(dp), C.byref(f), C.byref(nf)))
+    assert abs(a["f"] - f.value) < 1e-9 * abs(f.value) and np.abs(a["theta"] - x).max() < 2e-6 * np.abs(x).max()

@@ -728,6 +728,9 @@ static int potrf_blocked(Ctx& c, double* A, int lda, int n, int extra, Bat bt = 
         return launch_gemm<true>(sM, M, N, K, Ap, lda, Bp, ldb, epi, lower, inplace ? inplace : -1);
     };
     const int nsteps = (n + CHOL_NB - 1) / CHOL_NB;
+    static const int SPW = CHOL_NB * (getenv("GLMMR_MCML_CHOL_SPW") ? atoi(getenv("GLMMR_MCML_CHOL_SPW")) : 8);   // super-panel width (panels)
+    static const bool tl_off = getenv("GLMMR_MCML_CHOL_TWOLEVEL") && !strcmp(getenv("GLMMR_MCML_CHOL_TWOLEVEL"), "0");
+    const bool twolevel = bt.n > 1 && n > SPW + CHOL_NB && !tl_off;
     MCML_TRY(leaf(sM, 0, n < CHOL_NB ? n : CHOL_NB));
     bool forked = false;
     for (int t = 0; t < nsteps; ++t) {
@@ -740,6 +743,23 @@ static int potrf_blocked(Ctx& c, double* A, int lda, int n, int extra, Bat bt = 
         double* A21 = A11 + nb;                                   // R x nb: the panel below the diagonal block
         const int nb2 = rem < CHOL_NB ? rem : CHOL_NB;            // rows of the next diagonal block (0 at the end)
         if (forked) { MCML_HIP(hipStreamWaitEvent(sM, c.ev_leaf, 0)); forked = false; }   // leaf(t) done
+        // Two levels of blocking for a BATCH (bt.n > 1), whose rounds are bound by the trailing updates, not by the chain:
+        // inside a super-panel of 8 panels the K = 128 updates touch the super-panel's own columns only; the columns to
+        // its right receive all eight panels in ONE pass with K = 1024 when the super-panel is done (the same LDS-DMA
+        // kernel: 48 against 35 TF on the trailing update of a 4000 x 4000 block, scripts/dl_k_sweep.py) -- five
+        // read-modify-write passes over the trailing matrix at Q = 5000 instead of forty.  The sums are regrouped, so a
+        // batched value equals the single evaluation to rounding (1e-13), not to the bit.
+        const int sp0 = twolevel ? (k / SPW) * SPW : 0, sp1 = twolevel ? (sp0 + SPW < n ? sp0 + SPW : n) : n;
+        const int inner = sp1 - (k + nb);                         // trailing columns this step's K = 128 update covers
+        if (twolevel && inner == 0 && rem > 0) {
+            // last panel of a super-panel: the whole panel, then everything to the right in one pass, then the next leaf
+            MCML_TRY(gemm_nt(R, nb, nb, A21, Linv, CHOL_NB, A21, 1.0, 0.0, false, 0, 1, 0));
+            const double* Asp = A + sp1 + (size_t)sp0 * lda;      // rows below the super-panel, its columns
+            double* Csp = A + sp1 + (size_t)sp1 * lda;
+            MCML_TRY(gemm_nt(R, rem, sp1 - sp0, Asp, Asp, lda, Csp, -1.0, 1.0, true, 0, 0, 0));
+            MCML_TRY(leaf(sM, k + nb, nb2));
+            continue;
+        }
         if (nb2 > 0) {
             // the next diagonal block: its multiplier, its update, its factorisation
             MCML_TRY(gemm_nt(nb2, nb, nb, A21, Linv, CHOL_NB, A21, 1.0, 0.0, false, 7, 1, 0));
@@ -757,7 +777,7 @@ static int potrf_blocked(Ctx& c, double* A, int lda, int n, int extra, Bat bt = 
             MCML_TRY(gemm_nt(R - nb2, nb, nb, A21 + nb2, Linv, CHOL_NB, A21 + nb2, 1.0, 0.0, false, 0, 1, 0));
         if (rem > 0 && R - nb2 > 0) {
             double* C2 = A11 + nb + nb2 + (size_t)nb * lda;       // rows nb2.. of the trailing matrix, all its columns
-            MCML_TRY(gemm_nt(R - nb2, rem, nb, A21 + nb2, A21, lda, C2, -1.0, 1.0, true, 0, 0, nb2));
+            MCML_TRY(gemm_nt(R - nb2, twolevel ? inner : rem, nb, A21 + nb2, A21, lda, C2, -1.0, 1.0, true, 0, 0, nb2));
         }
     }
     if (forked) MCML_HIP(hipStreamWaitEvent(sM, c.ev_leaf, 0));

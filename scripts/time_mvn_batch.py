@@ -20,7 +20,7 @@ print("Q=%d m=%d sequential: %.3f ms per evaluation" % (Q, m, base * 1e3), flush
 for k in ks:
     T = np.array([th(i) for i in range(k)])
     for _ in range(3): got = ctx.mvn_ll_batch(T)          # eager, capture, replay
-    assert np.array_equal(got, np.array(ref[:k])), (got, ref[:k])
+    assert np.allclose(got, np.array(ref[:k]), rtol=1e-12, atol=0), (got, ref[:k])      # regrouped sums: equal to rounding
     t0 = time.perf_counter(); n = 6
     for i in range(n): ctx.mvn_ll_batch(T)
     dt = (time.perf_counter() - t0) / n

@@ -130,23 +130,31 @@ def test_unknown_family_link_is_an_error():
 
 
 def test_mvn_ll_batch_equals_single_evaluations(orc):
-    """glmmr_mcml_ctx_mvn_ll_batch: k candidate thetas on k evaluation lanes (own stream, workspace, captured graph)
-    give the very bits of k single evaluations, a non-positive-definite candidate comes back as NaN without disturbing
-    its neighbours, and the values agree with the oracle (mcmldmatrix.h:23-41)"""
+    """glmmr_mcml_ctx_mvn_ll_batch: k candidate thetas factorised side by side give the values of k single evaluations
+    (the very bits below the size at which the batch regroups its trailing updates into K = 1024 passes, 1e-12 above it),
+    the same bits on every repeat (eager, captured, replayed), a non-positive-definite candidate comes back as NaN
+    without disturbing its neighbours, and the values agree with the oracle (mcmldmatrix.h:23-41)"""
     from glmmrmcml_amd import api
-    for d, m in ((synth.geospatial(300, seed=2), 40), (synth.stepped_wedge(ncl=6, nt=4, nind=5), 16),
-                 (synth.cluster_rct(ncl=6, nt=4, nind=5), 12)):
+    for d, m in ((synth.geospatial(300, seed=2), 40), (synth.geospatial(1500, seed=2), 64),
+                 (synth.stepped_wedge(ncl=6, nt=4, nind=5), 16), (synth.cluster_rct(ncl=6, nt=4, nind=5), 12)):
         u = np.asfortranarray(np.random.default_rng(4).standard_normal((d["Q"], m)))
         with api.Context(d["cov"], d["data"], d["eff_range"]) as ctx:
             ctx.set_u(u)
             T = np.array([np.asarray(d["theta"]) * (1 + 0.05 * k) for k in range(5)])
             single = np.array([ctx.mvn_ll(t) for t in T])
+            first = None
             for rep in range(3):                       # eager, captured, replayed
                 got = ctx.mvn_ll_batch(T)
-                assert np.array_equal(got, single), (rep, got, single)
+                if d["Q"] <= 1024 + 128:
+                    assert np.array_equal(got, single), (rep, got, single)
+                else:
+                    assert np.allclose(got, single, rtol=1e-12, atol=0), (rep, got, single)
+                first = got if first is None else first
+                assert np.array_equal(got, first)
             assert np.array_equal(ctx.mvn_ll_batch(T[:1]), single[:1])
-            want = np.array([orc.mvn_ll(d["cov"], d["data"], d["eff_range"], t, u) for t in T])
-            assert np.abs(got - want).max() < 1e-10 * np.abs(want).max()
+            if d["Q"] <= 400:
+                want = np.array([orc.mvn_ll(d["cov"], d["data"], d["eff_range"], t, u) for t in T])
+                assert np.abs(got - want).max() < 1e-10 * np.abs(want).max()
     # a candidate outside the positive-definite region (an AR1 parameter of 1.5) is NaN; the others are untouched
     d = synth.stepped_wedge(ncl=6, nt=4, nind=5)
     u = np.asfortranarray(np.random.default_rng(4).standard_normal((d["Q"], 8)))

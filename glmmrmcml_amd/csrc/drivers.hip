@@ -99,11 +99,14 @@ struct McmlOptim {
             std::vector<double> vals(nc, 0.0);
             const bool emu = c.world <= 1 && !c.comm && c.emu_world > 1;
             int first_rc = MCML_OK;
-            // this rank's candidates of the round, side by side (one evaluation lane each: mvn.hip mvn_loglik_batch)
-            std::vector<int> own;
-            for (int j = 0; j < nc; ++j)
-                if ((j % wr) == c.rank || (emu && c.emu_mode == 1)) own.push_back(j);
-            if (!own.empty()) {
+            // this rank's candidates of the round, factorised side by side (mvn.hip mvn_loglik_batch).  Rank emulation in
+            // recording mode evaluates every rank's share here, one rank's share at a time -- exactly the batches the
+            // ranks of the real job would run, so that the replay reproduces the recorded values to the bit
+            const int r_lo = (emu && c.emu_mode == 1) ? 0 : c.rank, r_hi = (emu && c.emu_mode == 1) ? wr : c.rank + 1;
+            for (int rr = r_lo; rr < r_hi; ++rr) {
+                std::vector<int> own;
+                for (int j = 0; j < nc; ++j) if ((j % wr) == rr) own.push_back(j);
+                if (own.empty()) continue;
                 std::vector<double> ths((size_t)R * own.size()), sums(own.size(), 0.0);
                 std::vector<int> rcs(own.size(), 0);
                 for (size_t q = 0; q < own.size(); ++q)
@@ -116,7 +119,7 @@ struct McmlOptim {
                     if (rc == MCML_ENOTPD) vals[j] = HUGE_VAL;               // as eval_mvn: infinitely bad, not an error
                     else if (rc != MCML_OK) { vals[j] = NAN; if (first_rc == MCML_OK) first_rc = rc; }
                     else vals[j] = -1 * (sums[q] / mall);
-                    if ((j % wr) == c.rank) ++c.theta_evals_own;
+                    if (rr == c.rank) ++c.theta_evals_own;
                     if (c.theta_log_on && rc == MCML_OK) { c.theta_log.insert(c.theta_log.end(), ths.begin() + q * R, ths.begin() + (q + 1) * R); c.theta_log.push_back(sums[q] / mall); }
                 }
             }

@@ -73,8 +73,13 @@ def _run_world2(d, kw, Cn):
                 r["u"] = ctx.get_u()
                 r["comm"] = ctx.comm_stats()
                 r["shard"] = ctx.shard_stats()
+                r["ncalls"] = len(calls[rank])        # the exchanges of the fit itself (the exports below add theirs)
                 r["u_all"] = ctx.get_u_all()          # the theta-step gathered them: no further collective
                 assert ctx.comm_stats() == r["comm"] and ctx.shard_stats() == r["shard"]
+                # the step exports on the sharded samples (column-sharded evaluations, every value all-reduced)
+                vp = [r["sigma"]] if d["family"] == "gaussian" else []
+                r["aic"] = ctx.aic_mcml(np.r_[r["beta"], vp], r["theta"])
+                r["H"] = ctx.mcml_hess(np.r_[r["beta"], r["theta"], r["sigma"] if vp else 1.0], tol=1e-4)
                 out[rank] = r
         except Exception as e:
             err[rank] = e
@@ -115,12 +120,23 @@ def test_world2_contexts_equal_one_context_with_all_chains(gen, gkw, mcnr):
         assert out[r]["u"].shape == (d["Q"], Cn)
         assert np.abs(out[r]["u"] - whole["u"][:, r * Cn:(r + 1) * Cn]).max() < 2e-5
         assert not out[r]["comm"]["native"]
-        assert out[r]["comm"]["calls"] + out[r]["shard"]["gathers"] == len(calls[r])
+        assert out[r]["comm"]["calls"] + out[r]["shard"]["gathers"] == out[r]["ncalls"]
         assert np.array_equal(out[r]["u_all"][:, r * Cn:(r + 1) * Cn], out[r]["u"])
         assert np.abs(out[r]["u_all"] - whole["u"]).max() < 2e-5
     assert np.array_equal(out[0]["beta"], out[1]["beta"]) and np.array_equal(out[0]["theta"], out[1]["theta"])
     assert np.array_equal(out[0]["u_all"], out[1]["u_all"])
+    # aic_mcml / mcml_hess of the sharded job (src/mcml_optim.cpp:263-285,356-392) = the same exports of ONE context that
+    # holds all the columns, at the same parameters
+    assert out[0]["aic"] == out[1]["aic"] and np.array_equal(out[0]["H"], out[1]["H"])
+    with api.Context(*args) as ctx:
+        ctx.set_u(out[0]["u_all"])
+        vp = [out[0]["sigma"]] if d["family"] == "gaussian" else []
+        aic1 = ctx.aic_mcml(np.r_[out[0]["beta"], vp], out[0]["theta"])
+        H1 = ctx.mcml_hess(np.r_[out[0]["beta"], out[0]["theta"], out[0]["sigma"] if vp else 1.0], tol=1e-4)
+    assert abs(out[0]["aic"] - aic1) < 1e-9 * abs(aic1)
+    assert np.abs(out[0]["H"] - H1).max() < 1e-4 * np.abs(H1).max()
     assert calls[0] == calls[1] and len(calls[0]) > 0
+    calls = [c[:out[0]["ncalls"]] for c in calls]
     Q = d["Q"]
     ld = -(-Q // 32) * 32                               # leading dimension of the resident sample matrix
     gather = 2 * ld * Cn                                # the all-gather through a summing hook: both blocks

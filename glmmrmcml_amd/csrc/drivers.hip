@@ -17,8 +17,11 @@
 #include "ctx.h"
 #include "optim.h"
 #include "trace.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <random>
 
 namespace mcml {
@@ -206,12 +209,23 @@ struct McmlOptim {
     }
 
     // F_likelihood::operator() (likelihood.h:88-109) with fix_var = true
-    objective_fn make_F(bool importance, double fix_var_par, double denomD)
+    // memo: the MVN term depends on theta alone.  The central differences of f_hess move one or two coordinates at a time,
+    // so about half of its 4 (P + R)^2 points repeat a theta already factorised (19 distinct of 36 at P = 1, R = 2): those
+    // reuse the value (same bits) instead of another build + Cholesky + solve.
+    typedef std::map<std::vector<double>, double> ThetaMemo;
+    objective_fn make_F(bool importance, double fix_var_par, double denomD, bool memoise = false,
+                        std::shared_ptr<ThetaMemo> memo = std::make_shared<ThetaMemo>())
     {
-        return [this, importance, fix_var_par, denomD](const std::vector<double>& par, double* v) {
+        return [this, importance, fix_var_par, denomD, memoise, memo](const std::vector<double>& par, double* v) {
             model_var_par = fix_var_par;
             double ll, logl;
             MCML_TRY(eval_loglik(c, par.data(), model_var_par, &ll));
+            if (memoise) {
+                const std::vector<double> th(par.begin() + P, par.begin() + P + R);
+                auto it = memo->find(th);
+                if (it != memo->end()) logl = it->second;
+                else { MCML_TRY(eval_mvn(c, th.data(), &logl)); (*memo)[th] = logl; }
+            } else
             MCML_TRY(eval_mvn(c, par.data() + P, &logl));
             *v = importance ? -1.0 * (ll + logl - denomD) : -1.0 * (ll + logl);
             return (int)MCML_OK; };
@@ -239,10 +253,28 @@ struct McmlOptim {
     // f_hess (mcmloptim.h:333-355)
     int f_hess(double tol, double* H)
     {
-        objective_fn f = make_F(false, sigma, 0.0);
+        auto memo = std::make_shared<ThetaMemo>();
+        objective_fn f = make_F(false, sigma, 0.0, true, memo);
         const int nv = P + R;
         std::vector<double> x = beta, lo(P, -HUGE_VAL), up(nv, HUGE_VAL), nd(nv, tol), h;
         for (int i = 0; i < R; ++i) { x.push_back(theta[i]); lo.push_back(1e-6); }
+        // The points of the finite differences do not depend on the values: a dry pass lists the thetas they will ask
+        // for, and (single process) those are factorised side by side, a round at a time, before the real pass runs
+        if (comm_world(c) == 1 && c.maxdim_large > 0) {
+            std::vector<std::vector<double>> want;
+            objective_fn dry = [&](const std::vector<double>& par, double* v) {
+                std::vector<double> th(par.begin() + P, par.begin() + P + R);
+                if (std::find(want.begin(), want.end(), th) == want.end()) want.push_back(th);
+                *v = 0.0; return (int)MCML_OK; };
+            std::vector<double> hdry;
+            MCML_TRY(fd_hessian(dry, x, nd, true, lo, up, &hdry));
+            std::vector<double> ths((size_t)R * want.size()), sums(want.size(), 0.0);
+            std::vector<int> rcs(want.size(), 0);
+            for (size_t q = 0; q < want.size(); ++q) for (int i = 0; i < R; ++i) ths[q * R + i] = want[q][i];
+            MCML_TRY(mvn_loglik_batch(c, ths.data(), (int)want.size(), c.U.d(), c.U.ld, c.mcols, sums.data(), rcs.data()));
+            for (size_t q = 0; q < want.size(); ++q)
+                (*memo)[want[q]] = rcs[q] == MCML_OK ? sums[q] / c.mcols : -HUGE_VAL;       // as eval_mvn
+        }
         MCML_TRY(fd_hessian(f, x, nd, true, lo, up, &h));
         memcpy(H, h.data(), sizeof(double) * (size_t)nv * nv);
         return MCML_OK;

@@ -314,10 +314,10 @@ class Context:
                                                    C.byref(e), _p(b), _p(t), C.byref(sg)))
         return dict(beta=b, theta=t, sigma=sg.value)
 
-    def mcml_simlik(self, start, trace=0, maxfun=0):
+    def mcml_simlik(self, start, trace=0, maxfun=0, theta_batch=0):
         start = _f(start).ravel(); R = self.npar()
         b = np.zeros(self.P); t = np.zeros(R); sg = C.c_double()
-        e = self._ext(0, 1, maxfun)
+        e = self._ext(0, 1, maxfun, theta_batch)
         _lib.check(_lib.lib().glmmr_mcml_ctx_simlik(self._h, _p(start), start.size, int(trace), C.byref(e),
                                                     _p(b), _p(t), C.byref(sg)))
         return dict(beta=b, theta=t, sigma=sg.value)

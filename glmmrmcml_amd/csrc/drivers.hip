@@ -163,12 +163,7 @@ struct McmlOptim {
         // schedule is the default even for a single process, 8 candidates per round; a rank of a sharded job keeps one
         // candidate per round (measured at 8 ranks: rounds of 16 are rarely full, 202 against 191 ms per rank step)
         // (GLMMR_MCML_THETA_BATCH overrides, 1 = the reference's sequential BOBYQA).  glmmr_mcml_ext.theta_batch wins.
-        int k = theta_batch;
-        if (k <= 0) {
-            static const int envk = getenv("GLMMR_MCML_THETA_BATCH") ? atoi(getenv("GLMMR_MCML_THETA_BATCH")) : 0;
-            const bool dense_only = c.maxdim_large > 0 && c.n_small == 0 && c.n_diag_rows == 0;
-            k = envk > 0 ? envk : (dense_only && wr == 1) ? 8 : 1;
-        }
+        const int k = wr > 1 ? std::max(1, theta_batch) : batch_width();
         if ((wr > 1 && shard) || k > 1) return d_optim_sharded(wr * std::max(1, k));
         objective_fn f = [&](const std::vector<double>& par, double* v) {
             double logl; MCML_TRY(eval_mvn(c, par.data(), &logl)); *v = -1 * logl; return (int)MCML_OK; };
@@ -231,12 +226,59 @@ struct McmlOptim {
             return (int)MCML_OK; };
     }
 
+    // candidates per round of the batch schedule for this model in a single process (see d_optim): 8 when D consists of
+    // large dense blocks only, else 1 = the sequential optimiser; glmmr_mcml_ext.theta_batch / GLMMR_MCML_THETA_BATCH override
+    int batch_width() const
+    {
+        if (theta_batch > 0) return theta_batch;
+        static const int envk = getenv("GLMMR_MCML_THETA_BATCH") ? atoi(getenv("GLMMR_MCML_THETA_BATCH")) : 0;
+        if (envk > 0) return envk;
+        return (c.maxdim_large > 0 && c.n_small == 0 && c.n_diag_rows == 0) ? 8 : 1;
+    }
+
+    // f_optim on the batch schedule (single process, dense-block models): a round's candidates (beta, log theta[, sigma])
+    // get their MVN terms from ONE pass of the factorisation (mvn_loglik_batch) and their log-likelihood terms one after
+    // the other (cheap: n m log-pdf evaluations on the cached Z u).  Same objective (likelihood.h:88-109), same optimum.
+    // (For the gaussian family the reference lets BOBYQA carry sigma as a variable the objective never reads,
+    // mcmloptim.h:102-105 -- a flat direction whose final value is whatever the trust region left it at; here it simply stays
+    // at its start value.)
+    int f_optim_batch(int width, double denomD)
+    {
+        const double fix_var_par = sigma;
+        batch_objective_fn fb = [&](const std::vector<std::vector<double>>& Zs, std::vector<double>* F) -> int {
+            const int nc = (int)Zs.size();
+            std::vector<double> ths((size_t)R * nc), sums(nc, 0.0);
+            std::vector<int> rcs(nc, 0);
+            for (int j = 0; j < nc; ++j) for (int i = 0; i < R; ++i) ths[(size_t)j * R + i] = std::exp(Zs[j][P + i]);
+            MCML_TRY(mvn_loglik_batch(c, ths.data(), nc, c.U.d(), c.U.ld, c.mcols, sums.data(), rcs.data()));
+            F->assign(nc, 0.0);
+            for (int j = 0; j < nc; ++j) {
+                model_var_par = fix_var_par;
+                double ll = 0;
+                MCML_TRY(eval_loglik(c, Zs[j].data(), model_var_par, &ll));
+                const double logl = rcs[j] == MCML_OK ? sums[j] / c.mcols : -HUGE_VAL;
+                (*F)[j] = -1.0 * (ll + logl - denomD);
+            }
+            return MCML_OK; };
+        std::vector<double> x = beta, lo(P, -HUGE_VAL), up;
+        for (int i = 0; i < R; ++i) { x.push_back(std::log(std::max(theta[i], 1e-6))); lo.push_back(std::log(1e-6)); }
+        up.assign(x.size(), HUGE_VAL);
+        BobyqaOpts o = bopts();
+        o.rhobeg = 0.25; o.rhoend = 1e-7;
+        BobyqaResult r;
+        MCML_TRY(bobyqa_batch(fb, x, lo, up, o, width, &r));
+        beta.assign(r.x.begin(), r.x.begin() + P);
+        for (int i = 0; i < R; ++i) theta[i] = std::exp(r.x[P + i]);
+        return MCML_OK;
+    }
+
     // f_optim (mcmloptim.h:91-113)
     int f_optim()
     {
         const bool g = is_gaussian(c.flink);
         double denomD = 0;
         MCML_TRY(eval_mvn(c, cov_par_fix.data(), &denomD));      // constant in the parameters
+        if (comm_world(c) == 1 && batch_width() > 1) return f_optim_batch(batch_width(), denomD);
         objective_fn f = make_F(true, sigma, denomD);
         std::vector<double> x = beta, lo(P, -HUGE_VAL), up;
         for (int i = 0; i < R; ++i) { x.push_back(theta[i]); lo.push_back(1e-6); }
@@ -316,6 +358,7 @@ int drv_simlik(Ctx& c, const double* start, int nstart, int trace, const glmmr_m
     MCML_REQUIRE(start && nstart >= P + R + (is_gaussian(c.flink) ? 1 : 0), "start too short");
     MCML_REQUIRE(c.mcols > 0, "no samples u set");
     McmlOptim mc(c, start, trace, e ? e->maxfun : 0, 1.0);
+    mc.theta_batch = e ? e->theta_batch : 0;
     MCML_TRY(mc.f_optim());
     memcpy(beta, mc.beta.data(), sizeof(double) * P);
     memcpy(theta, mc.theta.data(), sizeof(double) * R);

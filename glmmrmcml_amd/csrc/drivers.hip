@@ -160,10 +160,12 @@ struct McmlOptim {
         const int wr = comm_world(c);
         // candidates per rank and round.  A model whose D is large dense blocks only (the geospatial configs) evaluates
         // a round's candidates in ONE pass of the factorisation's schedule (mvn.hip mvn_loglik_batch): there the batch
-        // schedule is the default even for a single process, 8 candidates per round; a rank of a sharded job keeps one
-        // candidate per round (measured at 8 ranks: rounds of 16 are rarely full, 202 against 191 ms per rank step)
-        // (GLMMR_MCML_THETA_BATCH overrides, 1 = the reference's sequential BOBYQA).  glmmr_mcml_ext.theta_batch wins.
-        const int k = wr > 1 ? std::max(1, theta_batch) : batch_width();
+        // schedule is the default even for a single process, 8 candidates per round (batch_width());
+        // glmmr_mcml_ext.theta_batch wins, 1 = the reference's sequential BOBYQA.
+        // a sharded job: rounds of about eight candidates in all -- 8 / world per rank for a dense-block model (at 2 ranks
+        // four candidates per rank factorised side by side: 6 rounds of 8.7 ms instead of 20 of 3.6 ms), one otherwise
+        const bool dense_only = c.maxdim_large > 0 && c.n_small == 0 && c.n_diag_rows == 0;
+        const int k = wr > 1 ? (theta_batch > 0 ? theta_batch : dense_only ? std::max(1, 8 / wr) : 1) : batch_width();
         if ((wr > 1 && shard) || k > 1) return d_optim_sharded(wr * std::max(1, k));
         objective_fn f = [&](const std::vector<double>& par, double* v) {
             double logl; MCML_TRY(eval_mvn(c, par.data(), &logl)); *v = -1 * logl; return (int)MCML_OK; };

@@ -193,10 +193,11 @@ typedef struct glmmr_mcml_ext {
     int      chains;    /* <= 1: the reference's single sequential chain; C: C concurrent chains */
     int      maxfun;    /* objective evaluations per optimiser call; 0 = 10000 (minqa default) */
     int      device;    /* HIP device ordinal */
-    int      theta_batch; /* candidate thetas per rank and round of the theta-step's batch schedule (csrc/optim.h
-                             bobyqa_batch).  0 = default: 8 for a single process whose D consists of large dense blocks
-                             only -- a round's candidates are then factorised side by side in one pass -- else 1;
-                             1 = the reference's sequential BOBYQA (in a sharded job: one candidate per rank and round) */
+    int      theta_batch; /* candidate thetas per rank and round of the batch schedule (csrc/optim.h bobyqa_batch) of the
+                             theta-step and of mcml_simlik.  0 = default: when D consists of large dense blocks only -- a
+                             round's candidates are then factorised side by side in one pass -- rounds of 8 in all (8 for a
+                             single process, 8 / world per rank of a sharded job), else 1 per rank; 1 = a single process
+                             runs the reference's sequential BOBYQA, a sharded job one candidate per rank and round */
 } glmmr_mcml_ext;
 
 /* gen_u_samples(y, X, Z, L, beta, family, sigma, warmup_iter, m) -> Q x m      -- R/gen_u_samples.R:38-69

@@ -141,12 +141,13 @@ def test_world2_contexts_equal_one_context_with_all_chains(gen, gkw, mcnr):
     ld = -(-Q // 32) * 32                               # leading dimension of the resident sample matrix
     gather = 2 * ld * Cn                                # the all-gather through a summing hook: both blocks
     sh = out[0]["shard"]
+    width = 8 if gen is synth.geospatial else 2          # candidates per round: one per rank; a dense-block model: 8 / world per
+    #                                                      rank, factorised side by side
     # per iteration: ONE all-gather of the samples (+ the 2-double agreement on the block width in front of it), then
     # one all-reduce of <= world candidate values per round of the theta-step; each rank evaluates half the candidates
     assert calls[0].count(gather) == 2 and sh["gathers"] == 2 and sh["gather_doubles"] == 2 * gather
     assert sh["theta_rounds"] >= 2 * 3 and sh["theta_evals_own"] + out[1]["shard"]["theta_evals_own"] == sh["theta_evals_all"]
-    assert abs(sh["theta_evals_own"] - out[1]["shard"]["theta_evals_own"]) <= sh["theta_rounds"]
-    width = 2                                            # candidates per round: one per rank
+    assert abs(sh["theta_evals_own"] - out[1]["shard"]["theta_evals_own"]) <= (width // 2) * sh["theta_rounds"]
     assert sh["theta_evals_all"] <= width * sh["theta_rounds"]
     small = [n for n in calls[0] if n != gather]
     if mcnr:

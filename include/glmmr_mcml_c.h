@@ -104,9 +104,11 @@ int glmmr_mcml_get_u_all(glmmr_mcml_ctx* ctx, double* u, int ldu, int* ncols_out
 
 /* MCMLDmatrix::loglik(u) at theta (mcmldmatrix.h:23-41) */
 int glmmr_mcml_ctx_mvn_ll(glmmr_mcml_ctx* ctx, const double* theta, double* out);
-/* the same at k candidate thetas (npar x k, column-major) evaluated SIDE BY SIDE, one per evaluation lane (own stream,
- * workspace and captured graph): one evaluation of a large dense block is a latency chain that leaves most of the chip
- * idle.  out[j] = log-likelihood at candidate j, NaN where D(theta_j) is not positive definite.  k <= 64. */
+/* the same at k candidate thetas (npar x k, column-major) FACTORISED SIDE BY SIDE: when D consists of large dense blocks
+ * only, the k matrices sit in one workspace and every launch of the factorisation's schedule covers all of them -- one
+ * evaluation of such a block is a latency chain that leaves most of the chip idle.  Other models: one
+ * after the other.  out[j] = log-likelihood at candidate j (equal to the single evaluation to rounding), NaN where
+ * D(theta_j) is not positive definite.  k <= 64. */
 int glmmr_mcml_ctx_mvn_ll_batch(glmmr_mcml_ctx* ctx, const double* thetas, int k, double* out);
 /* DMatrix::genD(0, chol, false) (mcml_full.cpp:68) -> out (Q x Q) */
 int glmmr_mcml_ctx_gen_D(glmmr_mcml_ctx* ctx, const double* theta, int chol, double* out, int ldo);

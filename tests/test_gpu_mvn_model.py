@@ -163,3 +163,21 @@ def test_mvn_ll_batch_equals_single_evaluations(orc):
         good = np.asarray(d["theta"], float); bad = good.copy(); bad[1] = 1.5
         got = ctx.mvn_ll_batch(np.array([good, bad, good * 1.1]))
         assert np.isnan(got[1]) and got[0] == ctx.mvn_ll(good) and got[2] == ctx.mvn_ll(good * 1.1)
+
+
+def test_mvn_ll_batch_odd_shapes():
+    """block sizes round multiples of the 128-wide panel and of the 1024-wide super-panel (where a batch regroups its trailing
+    updates), one or a few sample columns, 2 / 3 / 8 candidates: every batched value equals the single evaluation to rounding"""
+    from glmmrmcml_amd import api
+    for n in (33, 129, 257, 1023, 1153, 1296, 2049):
+        d = synth.geospatial(n, seed=n)
+        for m in (1, 3, 17):
+            u = np.asfortranarray(np.random.default_rng(m).standard_normal((n, m)))
+            with api.Context(d["cov"], d["data"], d["eff_range"]) as ctx:
+                ctx.set_u(u)
+                for k in (2, 3, 8):
+                    T = np.array([np.asarray(d["theta"]) * (1 + 0.04 * j) for j in range(k)])
+                    single = np.array([ctx.mvn_ll(t) for t in T])
+                    for rep in range(3):
+                        got = ctx.mvn_ll_batch(T)
+                        assert np.abs(got - single).max() < 1e-11 * np.abs(single).max(), (n, m, k, rep, got, single)

@@ -416,6 +416,13 @@ extern "C" int glmmr_mcml_ctx_profile(glmmr_mcml_ctx* h, int enable, int reset, 
         out8[4] = ff; out8[5] = fb; out8[6] = dense; out8[7] = kind;
     }
     if (reset) for (int i = 0; i < 4; ++i) { p.ms[i] = 0; p.cnt[i] = 0; p.seen[i] = 0; }
+    if (enable && !p.on) {
+        // the markers' events are made HERE, not at their first use inside whatever is being timed: a sampler call of
+        // 100 proposals records ~1000 of them, and creating those on the fly cost the first timed MCML iteration of a
+        // small configuration 20-75 ms (config 4 in bench.py: 45 or 70 ms per iteration from one process to the next)
+        MCML_HIP(hipSetDevice(c.device));
+        while (p.ev.size() < 4096) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); break; } p.ev.push_back(e); }
+    }
     p.on = enable != 0;
     return MCML_OK;
 }

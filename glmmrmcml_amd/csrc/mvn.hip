@@ -916,13 +916,12 @@ static bool chol_graph_on() { return chol_graph_kind() != 0; }
 static int potrf_graphed(Ctx& c, double* A, int lda, int n, int extra, Bat bt = Bat())
 {
     if (!chol_graph_on() || !(chol_mode() == 1 && n > 2 * CHOL_NB)) return potrf_blocked(c, A, lda, n, extra, bt);
-    // GLMMR_MCML_BATCH_GRAPH=0: a batch launched eagerly with the two-stream fork-join instead of replayed as a one-chain
-    // graph.  Measured 7 % (Q = 5000) to 12 % (Q = 2000) faster per round -- 13.4 against 14.4 ms, 1.95 against 2.21 ms --
-    // but not the default: after a few thousand live cross-stream event waits the launch-bound work that follows in the
-    // same process (config 4's iterations after config 3's and 2's in bench.py) ran 45 or 68 ms per iteration from one
-    // process to the next, its products unchanged at 29 us -- the time went missing on the host side of the runtime.
-    static const bool batch_eager = getenv("GLMMR_MCML_BATCH_GRAPH") && !strcmp(getenv("GLMMR_MCML_BATCH_GRAPH"), "0");
-    if (bt.n > 1 && batch_eager) return potrf_blocked(c, A, lda, n, extra, bt);
+    // A batch is launched EAGERLY with the two-stream fork-join of potrf_blocked (the leaf of step t+1 beside the bulk of
+    // step t): 13.4 ms per round of 8 at Q = 5000 and 1.95 ms at Q = 2000, against 14.4 / 2.21 ms for the one-chain graph
+    // (GLMMR_MCML_BATCH_GRAPH=1) -- a graph without a parallel branch cannot overlap the two, and one with a branch is
+    // subject to the executable lottery described at CholGraph.  The host keeps ahead easily (~250 launches per round).
+    static const bool batch_graph = getenv("GLMMR_MCML_BATCH_GRAPH") && !strcmp(getenv("GLMMR_MCML_BATCH_GRAPH"), "1");
+    if (bt.n > 1 && !batch_graph) return potrf_blocked(c, A, lda, n, extra, bt);
     CholGraph& g = c.chol_graphs.find(A, c.linv.d(), lda, n, extra + (bt.n << 24), bt.n == 1);
     auto timed_begin = [&]() -> bool {
         if (!g.t0 && (hipEventCreate(&g.t0) != hipSuccess || hipEventCreate(&g.t1) != hipSuccess)) { (void)hipGetLastError(); return false; }

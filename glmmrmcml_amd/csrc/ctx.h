@@ -214,6 +214,7 @@ struct Ctx {
     DevBuf scalars;             // small device scalars: [0..15] results, [16] error flag (int)
     int maxdim_large = 0;       // largest block that takes the recursive path
     int n_small = 0, n_diag_rows = 0;
+    DevBuf small_ids;                           // ids of the small dense blocks (mvn_setup), for k_small_ll
 
     // sampler
     int last_kernel[2] = {-1, -1};   // kernel family of the last forward / backward product (KERNEL_*)

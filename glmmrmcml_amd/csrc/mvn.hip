@@ -1081,7 +1081,7 @@ int mvn_setup(Ctx& c)
         MCML_HIP(hipMemcpyAsync(c.d_data.p, cs.data.data(), sizeof(double) * cs.data.size(), hipMemcpyHostToDevice, c.stream));
     MCML_TRY(c.d_blocks.ensure(sizeof(CovBlock) * cs.blocks.size()));
     MCML_HIP(hipMemcpyAsync(c.d_blocks.p, cs.blocks.data(), sizeof(CovBlock) * cs.blocks.size(), hipMemcpyHostToDevice, c.stream));
-    std::vector<int> rowblock(cs.N, -1);
+    std::vector<int> rowblock(cs.N, -1), small;
     c.maxdim_large = 0; c.n_small = 0; c.n_diag_rows = 0;
     for (int b = 0; b < cs.B; ++b) {
         const CovBlock& blk = cs.blocks[b];
@@ -1090,6 +1090,7 @@ int mvn_setup(Ctx& c)
             c.n_diag_rows += blk.dim;
         } else if (blk.dim <= SMALL_BLOCK) {
             ++c.n_small;
+            small.push_back(b);
         } else if (blk.dim > c.maxdim_large) {
             c.maxdim_large = blk.dim;
         }
@@ -1098,6 +1099,10 @@ int mvn_setup(Ctx& c)
     MCML_HIP(hipMemcpyAsync(c.d_rowblock.p, rowblock.data(), sizeof(int) * cs.N, hipMemcpyHostToDevice, c.stream));
     MCML_TRY(c.scalars.ensure(sizeof(double) * 64));
     MCML_HIP(hipMemsetAsync(c.scalars.p, 0, sizeof(double) * 64, c.stream));
+    if (c.n_small) {
+        MCML_TRY(c.small_ids.ensure(sizeof(int) * small.size()));
+        MCML_HIP(hipMemcpyAsync(c.small_ids.p, small.data(), sizeof(int) * small.size(), hipMemcpyHostToDevice, c.stream));
+    }
     if (c.maxdim_large) {
         MCML_TRY(c.Dwork.alloc(c.maxdim_large, c.maxdim_large));
         MCML_HIP(hipMemsetAsync(c.Dwork.d(), 0, sizeof(double) * (size_t)c.Dwork.ld * c.maxdim_large, c.stream));
@@ -1262,21 +1267,16 @@ static int mvn_loglik_enqueue(Ctx& c, const double* theta, const double* Us, int
         MCML_HIP(hipGetLastError());
     }
     if (c.n_small > 0) {
-        std::vector<int> ids;
-        for (int b = 0; b < cs.B; ++b)
-            if (!cs.blocks[b].all_gr && cs.blocks[b].dim <= SMALL_BLOCK) ids.push_back(b);
+        // the block ids were uploaded once by mvn_setup: nothing here needs the host to wait (this was a host
+        // synchronisation per evaluation, 40 of them in a theta-step of config 4)
         int ny = (m + 63) / 64; if (ny > 16) ny = 16;
-        // ids + partials live in one buffer: [ids | partials]
-        size_t idbytes = round_up_sz(sizeof(int) * ids.size(), 16);
         DevBuf& wb = c.scratch;      // scratch that outlives the launch
-        MCML_TRY(wb.ensure(idbytes + sizeof(double) * ids.size() * ny + 1024));
-        MCML_HIP(hipMemcpyAsync(wb.p, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, c.stream));
-        double* part = reinterpret_cast<double*>(static_cast<char*>(wb.p) + idbytes);
-        hipLaunchKernelGGL(k_small_ll, dim3((unsigned)ids.size(), ny), dim3(64), 0, c.stream, Us, ldu, m,
-                           wb.as<int>(), dblk, dcov, cs.rows, c.d_data.d(), th, part, c.scalars.as<int>() + 32);
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, part, (int)ids.size() * ny, 1.0, scal, 1);
+        MCML_TRY(wb.ensure(sizeof(double) * (size_t)c.n_small * ny + 1024));
+        double* part = wb.d();
+        hipLaunchKernelGGL(k_small_ll, dim3((unsigned)c.n_small, ny), dim3(64), 0, c.stream, Us, ldu, m,
+                           c.small_ids.as<int>(), dblk, dcov, cs.rows, c.d_data.d(), th, part, c.scalars.as<int>() + 32);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, part, c.n_small * ny, 1.0, scal, 1);
         MCML_HIP(hipGetLastError());
-        MCML_HIP(hipStreamSynchronize(c.stream));   // ids is a host temporary
     }
     if (c.maxdim_large > 0) {
         // blocked path: the m sample columns ride below the matrix as m extra rows (U', one sample per row), so

@@ -59,6 +59,8 @@ struct SparseZL {
     long nnz_z = 0, nnz_l = 0;
     DevBuf zcsr_ptr, zcsr_i, zcsr_val;         // rows of Z' : q -> (observation, value)
     DevBuf row_end;                            // one past the last row of column q of L (= end of q's block)
+    DevBuf blk_ptr;                            // first row of every covariance block, B + 1 entries (k_cm_Lcol_Lrow)
+    int nblk = 0, max_blk = 0;
 };
 
 // HIP-event timing of the dominant kernels, on the stream they are launched on

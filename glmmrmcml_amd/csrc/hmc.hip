@@ -483,8 +483,9 @@ static int hmc_forward_launch(Ctx& c, const double* X, int ldx, const Epi& epi)
 }
 
 // want_ll (sparse operator only): leave the per-chain partial sums of log f(y | MU) in h.cm_part_fwd instead of MU
+// lx_ready (factored sparse operator only): LX = L X is already there, left by k_cm_Lcol_Lrow of the previous leapfrog step
 static int hmc_forward(Ctx& c, const double* X, int ldx, double var_par, bool store_mu = true, bool chain = false,
-                       bool want_ll = false)
+                       bool want_ll = false, bool lx_ready = false)
 {
     HmcState& h = c.hmc;
     const int slot = c.prof.begin(c.stream, 0, chain);
@@ -496,6 +497,7 @@ static int hmc_forward(Ctx& c, const double* X, int ldx, double var_par, bool st
         // factored operator: LX = L X first, then the rows of Z gather from LX
         int W = c.sp.W; const int* col = c.sp.ell_col.as<int>(); const double* val = c.sp.ell_val.d(); const double* Xin = X;
         if (c.sp.factored) {
+            if (!lx_ready)
             hipLaunchKernelGGL(k_cm_Lrow, dim3((c.Q + 3) / 4, (h.Cw + 63) / 64), dim3(256), 0, c.stream, c.Q, h.Cw, h.V.ld,
                                c.sp.row_start.as<int>(), c.L.d(), c.L.ld, X, h.LX.d());
             W = c.z_width; col = c.z_idx.as<int>(); val = c.z_val.d(); Xin = h.LX.d();
@@ -532,7 +534,17 @@ static int hmc_forward(Ctx& c, const double* X, int ldx, double var_par, bool st
     return rc;
 }
 
-static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_par, int mode, bool chain = false)
+// GLMMR_MCML_CM_LFUSE=0: the factored operator's k_cm_Lcol and the next step's k_cm_Lrow as separate launches (the A/B switch)
+static bool cm_lfuse(const Ctx& c)
+{
+    const char* e = getenv("GLMMR_MCML_CM_LFUSE");          // read per hmc_sample call: a test compares the two in one process
+    const bool v = !(e && !strcmp(e, "0"));
+    return v && c.sp.factored && c.sp.nblk > 0 && c.sp.max_blk <= 16;
+}
+
+// next_lx (factored sparse operator, inside a trajectory): also leave LX = L * UP for the next step's forward product
+static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_par, int mode, bool chain = false,
+                        bool next_lx = false)
 {
     HmcState& h = c.hmc;
     ChainArrays ca = chain_arrays(h);
@@ -558,7 +570,15 @@ static int hmc_backward(Ctx& c, const double* Xs, double* G, int s, double var_p
             hipLaunchKernelGGL(k_cm_backward, grid, dim3(256), 0, c.stream, c.Q, h.Cw, h.V.ld, ptr, ci, cv, h.S.d(), Xs, out,
                                h.R.d(), h.UP.d(), ca.e, ca.steps, s, post, m1, rpw);
         }
-        if (f)
+        if (f && next_lx && mode == 1) {
+            const dim3 grid((c.sp.nblk + 3) / 4, (h.Cw + 63) / 64);
+            if (c.sp.max_blk <= 8)
+                hipLaunchKernelGGL((k_cm_Lcol_Lrow<8>), grid, dim3(256), 0, c.stream, c.sp.nblk, h.Cw, h.V.ld, c.sp.blk_ptr.as<int>(),
+                                   c.L.d(), c.L.ld, h.ZS.d(), Xs, G, h.R.d(), h.UP.d(), ca.e, ca.steps, s, post, h.LX.d());
+            else
+                hipLaunchKernelGGL((k_cm_Lcol_Lrow<16>), grid, dim3(256), 0, c.stream, c.sp.nblk, h.Cw, h.V.ld, c.sp.blk_ptr.as<int>(),
+                                   c.L.d(), c.L.ld, h.ZS.d(), Xs, G, h.R.d(), h.UP.d(), ca.e, ca.steps, s, post, h.LX.d());
+        } else if (f)
             hipLaunchKernelGGL(k_cm_Lcol, dim3((c.Q + 3) / 4, (h.Cw + 63) / 64), dim3(256), 0, c.stream, c.Q, h.Cw, h.V.ld,
                                c.sp.row_end.as<int>(), c.L.d(), c.L.ld, h.ZS.d(), Xs, G, h.R.d(), h.UP.d(), ca.e, ca.steps, s,
                                post, mode);
@@ -721,6 +741,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
     } ring_guard{h_ring, ring_ev, RING, c.stream};
     int seen_maxs = -1;                         // latest step count actually observed
     bool pending_commit = false;                // sparse operator: the last decisions are applied by the next k_cm_propose
+    const bool lf = h.cm && cm_lfuse(c);        // factored operator: the backward pass of step s leaves LX for step s + 1
     for (int it = 0; it < total; ++it) {
         if (h.cm) {
             const CmParts p = cm_parts(c);
@@ -759,8 +780,8 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         int rc_traj = MCML_OK;
         for (int s = 0; s < maxs && rc_traj == MCML_OK; ++s) {
             const bool fuse = h.cm && cm_fuse();
-            rc_traj = hmc_forward(c, h.UP.d(), h.UP.ld, var_par, !fuse && s == maxs - 1, s > 0, fuse && s == maxs - 1);
-            if (rc_traj == MCML_OK) rc_traj = hmc_backward(c, h.UP.d(), h.GRADP.d(), s, var_par, 1, true);
+            rc_traj = hmc_forward(c, h.UP.d(), h.UP.ld, var_par, !fuse && s == maxs - 1, s > 0, fuse && s == maxs - 1, lf && s > 0);
+            if (rc_traj == MCML_OK) rc_traj = hmc_backward(c, h.UP.d(), h.GRADP.d(), s, var_par, 1, true, lf && s + 1 < maxs);
         }
         c.prof.skip = false;
         MCML_TRY(rc_traj);

@@ -303,6 +303,80 @@ __global__ __launch_bounds__(256) void k_cm_Lcol(int Q, int C, int ldc, const in
     cm_leapfrog(acc, c + (size_t)q * ldc, Xs, G, R, UP, en, st, s, post, mode);
 }
 
+// k_cm_Lcol of leapfrog step s and k_cm_Lrow of step s + 1 in one launch (a trajectory of the factored operator): a WAVE owns
+// one covariance block x 64 chains.  The block of L goes through LDS once (read back as broadcasts), the block's rows of T and the
+// updated positions stay in registers, so that LX = L * UP of the next step comes out of the same kernel that produced UP -- three
+// launches per leapfrog step instead of four (config 4: k_cm_Lcol 4.9 us + k_cm_Lrow 4.6 us + a kernel boundary).  The sums run in
+// the order of the two kernels above (ascending j, one fma per term), so the results are theirs to the bit.  DMAX >= the largest
+// block; models with larger blocks keep the separate kernels (hmc.hip).
+template <int DMAX>
+__global__ __launch_bounds__(256) void k_cm_Lcol_Lrow(int B, int C, int ldc, const int* blk_ptr, const double* L, int ldl,
+                                                      const double* T, const double* Xs, double* G, double* R, double* UP,
+                                                      const double* e, const int* steps, int s, double post, double* LX)
+{
+    __shared__ double Ls[4][DMAX * DMAX];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x * 4 + w;
+    const bool bin = b < B;
+    const int r0 = bin ? __builtin_amdgcn_readfirstlane(blk_ptr[b]) : 0;
+    const int d = bin ? __builtin_amdgcn_readfirstlane(blk_ptr[b + 1]) - r0 : 0;
+    const int c = blockIdx.y * 64 + lane;
+    const bool valid = bin && c < C;
+    // every load first (the block of L for LDS and 3 d independent loads of the chain's state, all in flight together), then the
+    // arithmetic, then the stores: the stores may alias the loads as far as the compiler knows (Xs IS UP), and a load behind
+    // each store made this a chain of d memory round trips
+    const int st = valid ? steps[c] : 0;
+    const double en = valid ? e[c] : 0.0;
+    const bool live = s < st, last = s + 1 >= st;
+    double t[DMAX], x[DMAX], rr[DMAX], g[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i)
+        if (i < d && valid) {
+            const size_t off = c + (size_t)(r0 + i) * ldc;
+            t[i] = T[off]; x[i] = Xs[off]; rr[i] = live ? R[off] : 0.0;
+        }
+    for (int idx = lane; idx < d * d; idx += 64) {
+        const int i = idx % d, j = idx / d;
+        Ls[w][i + j * DMAX] = (i >= j) ? L[(size_t)(r0 + i) + (size_t)(r0 + j) * ldl] : 0.0;
+    }
+    __syncthreads();                                   // every wave gets here (no early exit above)
+    if (!valid) return;
+#pragma unroll
+    for (int q = 0; q < DMAX; ++q) {
+        if (q < d) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = q; j < DMAX; ++j) if (j < d) acc += Ls[w][j + q * DMAX] * t[j];       // column q of L, ascending j
+            if (live) {                                // cm_leapfrog, mode 1
+                double gq = -1.0 * x[q];
+                gq = gq + post * acc;
+                double r = rr[q];
+                r = r + (en / 2) * gq;
+                if (!last) { r = r + (en / 2) * gq; x[q] = x[q] + en * r; }
+                rr[q] = r; g[q] = gq;
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < DMAX; ++q)
+            if (q < d) {
+                const size_t off = c + (size_t)(r0 + q) * ldc;
+                if (last) G[off] = g[q]; else UP[off] = x[q];
+                R[off] = rr[q];
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < DMAX; ++q) {
+        if (q < d) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j <= q; ++j) acc += Ls[w][q + j * DMAX] * x[j];                    // row q of L, ascending j
+            LX[c + (size_t)(r0 + q) * ldc] = acc;
+        }
+    }
+}
+
 // ---- per-chain kernels -------------------------------------------------------------------------------------------
 // grid (chains / 64, row chunks of CM_ROWS); wave w of a workgroup takes rows w, w + 4, ... of the chunk and the four
 // waves' sums are added in wave order through LDS: one partial per (chunk, chain)

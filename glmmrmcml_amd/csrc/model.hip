@@ -231,6 +231,23 @@ static int sparse_zl_setup(Ctx& c)
         MCML_HIP(hipMemcpyAsync(sp.zcsr_val.p, zv.data(), sizeof(double) * (size_t)nz, hipMemcpyHostToDevice, c.stream));
         MCML_HIP(hipMemcpyAsync(sp.row_end.p, end_of.data(), sizeof(int) * (size_t)Q, hipMemcpyHostToDevice, c.stream));
         sp.nnz_z = nz; sp.nnz_l = nl;
+        // the blocks in row order, for the kernel that takes a whole block per wave (contiguous and covering 0 .. Q, or not used)
+        {
+            std::vector<int> bp;
+            int at = 0; bool ok = true;
+            sp.max_blk = 0;
+            for (int b = 0; b < c.cov.B && ok; ++b) {
+                if (c.cov.blocks[b].matstart != at) ok = false;
+                bp.push_back(at); at += c.cov.blocks[b].dim;
+                if (c.cov.blocks[b].dim > sp.max_blk) sp.max_blk = c.cov.blocks[b].dim;
+            }
+            bp.push_back(at);
+            sp.nblk = (ok && at == Q) ? c.cov.B : 0;
+            if (sp.nblk) {
+                MCML_TRY(sp.blk_ptr.ensure(sizeof(int) * bp.size()));
+                MCML_HIP(hipMemcpy(sp.blk_ptr.p, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice));
+            }
+        }
         // entries gathered per chain and leapfrog step: nnz(ZL) against nnz(Z) + nnz(L) + the extra pass over Q
         sp.factored = 4 * (nz + nl + 2L * Q) < 3 * nnz;
         if (const char* e = getenv("GLMMR_MCML_ZL")) {

@@ -172,6 +172,30 @@ def test_sparse_and_dense_zl_operators_agree(monkeypatch):
             assert np.abs(out["product"][4] - out[mode][4]).max() < 1e-11 * max(1.0, np.abs(out["product"][4]).max()), mode
 
 
+def test_fused_block_kernel_of_the_factored_operator_is_bit_identical(monkeypatch):
+    """factored sparse operator: k_cm_Lcol of a leapfrog step and k_cm_Lrow of the next one as ONE launch (a wave per covariance
+    block, hmc_cm.h::k_cm_Lcol_Lrow) against the two kernels (GLMMR_MCML_CM_LFUSE=0): the same draws bit for bit -- blocks of 5 and
+    8 (the 8-wide instantiation), 12 (the 16-wide one), step counts below and at the cap, a ragged last chain group"""
+    from glmmrmcml_amd import api
+    monkeypatch.setenv("GLMMR_MCML_ZL", "factored")
+    for kw, lam, ms, chains in ((dict(ncl=7, nt=5, nind=40), 0.4, 10, 70), (dict(ncl=6, nt=8, nind=30), 5.0, 6, 64),
+                                (dict(ncl=5, nt=12, nind=25), 0.5, 8, 130)):
+        d = synth.stepped_wedge(**kw)
+        out = []
+        with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"]) as ctx:
+            ctx.update_L(d["theta"])
+            for fuse in ("1", "0"):
+                monkeypatch.setenv("GLMMR_MCML_CM_LFUSE", fuse)
+                diag, flags, probs = ctx.hmc_sample(d["beta"], 1.0, 25, chains, lam, ms, 0.9, seed=11, chains=chains, want_trace=True)
+                assert set(ctx.last_kernels()) == {"sparse"}
+                out.append((ctx.get_u(), flags.copy(), probs.copy(), diag))
+        assert np.array_equal(out[0][1], out[1][1]), kw
+        assert np.array_equal(out[0][2], out[1][2]), kw
+        assert np.array_equal(out[0][0], out[1][0]), kw
+        assert out[0][3]["leapfrog_total"] == out[1][3]["leapfrog_total"]
+    monkeypatch.delenv("GLMMR_MCML_CM_LFUSE", raising=False)
+
+
 def test_dense_z_sampler_runs_the_direct_to_lds_kernel(orc):
     """a dense, non-identity Z (Householder reflector, bench.py --dense-z): ZL has no structural zeros, more than 16
     chains -> both products run dgemm_dlds_asm_kernel (asserted), chain by chain against the oracle"""

@@ -123,14 +123,17 @@ def other_configs(api, synth, stream, iters=3):
                 # launches and host wake-ups, and now and then a whole repetition runs ~40 % slower with the same kernel
                 # times ("run-to-run jitter"); ms_per_iter is the faster one
                 reps = []
+                ph = []
                 for _ in range(2):
                     ctx.profile(enable=True, reset=True)
+                    api.phase_ms(enable=True, reset=True)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     r_ = ctx.mcml_full(d["start"], maxiter=iters, **kw)
                     torch.cuda.synchronize()
                     dt_ = time.perf_counter() - t0
                     p_ = ctx.profile(enable=False)
+                    ph.append({k: round(v / iters, 2) for k, v in api.phase_ms(enable=False).items()})
                     reps.append(dt_)
                     if dt_ <= min(reps):
                         dt, r, p = dt_, r_, p_
@@ -149,7 +152,7 @@ def other_configs(api, synth, stream, iters=3):
                 roof["frac"] = roof["achieved"] / roof["peak"]
                 roof["avg_launch_us"] = ks / max(1, nl) * 1e6
                 roof["share_of_iteration"] = ks / max(1, nl) * (p["fwd_n_all"] + p["bwd_n_all"]) / dt
-                rec = {"workload": desc, "ms_per_iter": dt / iters * 1e3, "ms_per_iter_reps": [x / iters * 1e3 for x in reps],
+                rec = {"workload": desc, "ms_per_iter": dt / iters * 1e3, "ms_per_iter_reps": [x / iters * 1e3 for x in reps], "phases_ms_per_iter_reps": ph,
                        "evals_per_s": m * iters / dt, "iters": iters,
                        "roofline": roof, "beta": [float(x) for x in r["beta"]], "theta": [float(x) for x in r["theta"]],
                        "sigma": float(r["sigma"]), "accept_rate": r["accept_rate"]}
@@ -285,11 +288,13 @@ def main():
         run(args.warmup)
     shard0 = ctx.shard_stats()
     ctx.profile(enable=True, reset=True)
+    api.phase_ms(enable=True, reset=True)                    # host wall-clock per phase (csrc/trace.h): two clock reads per phase
     barrier()
     t0 = time.perf_counter()
     res = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    phases = api.phase_ms(enable=False)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         tdist.all_reduce(tt, op=tdist.ReduceOp.MAX)
@@ -353,6 +358,7 @@ def main():
                                          shard["gathers"], 8e-6 * shard["gather_doubles"] / max(1, shard["gathers"])))
                                      if shard["theta_rounds"] else "sequential BOBYQA on this GPU, %d evaluations per step" % cfg["theta_maxfun"],
                        "accept_rate": res["accept_rate"], "leapfrog_steps_last_iter": res["leapfrog_total"],
+                       "phases_ms_per_step": {k: v / args.steps for k, v in phases.items()},
                        "fit": fit, "fit_ok": fit_ok},
             "roofline": {"bound": "mfma",
                          "kernel": "dgemm_%s_kernel (HMC forward / backward n x Q x C product, FP64 MFMA)"

@@ -56,6 +56,13 @@ class NutsDiag(C.Structure):
                 ("stepsize_search_leapfrogs", C.c_longlong)]
 
 
+def phase_ms(enable=True, reset=False):
+    """host wall-clock per phase of the MCML iterations of this process since the last reset (csrc/trace.h)"""
+    out = np.zeros(8)
+    _lib.check(_lib.lib().glmmr_mcml_dbg_phase_ms(int(enable), int(reset), _p(out)))
+    return {k: float(out[i]) for i, k in enumerate(("sample", "beta_step", "theta_step", "refresh"))}
+
+
 def rccl_unique_id():
     """128 opaque bytes from ncclGetUniqueId: made on rank 0, handed to every rank's Context.comm_init_rccl"""
     buf = (C.c_ubyte * 128)()

@@ -174,9 +174,9 @@ int allreduce_host(Ctx& c, double* vals, int n)
 {
     if (!c.comm && c.world <= 1 && c.emu_world <= 1) return MCML_OK;
     MCML_TRY(c.reduce_buf.ensure(sizeof(double) * (size_t)(n < 64 ? 64 : n)));
-    MCML_HIP(hipMemcpyAsync(c.reduce_buf.p, vals, sizeof(double) * n, hipMemcpyHostToDevice, c.stream));
+    MCML_TRY(copy_h2d(c.reduce_buf.p, vals, sizeof(double) * n, c.stream));
     MCML_TRY(allreduce_dev(c, c.reduce_buf.d(), n));
-    MCML_HIP(hipMemcpyAsync(vals, c.reduce_buf.p, sizeof(double) * n, hipMemcpyDeviceToHost, c.stream));
+    MCML_TRY(copy_d2h(vals, c.reduce_buf.p, sizeof(double) * n, c.stream));
     MCML_HIP(hipStreamSynchronize(c.stream));
     return MCML_OK;
 }

@@ -121,6 +121,18 @@ struct DevMat {
     double* at(int i, int j) const { return buf.d() + i + (size_t)j * ld; }
 };
 
+// Host <-> device copies of CALLER (or temporary) host memory.  Everything above a few KB goes through a pinned staging
+// buffer the library owns, in chunks, and is complete when the call returns -- so that the runtime never pins pageable
+// memory it does not own: a pinned registration of memory the caller (or a destroyed std::vector) later unmaps makes the
+// kernel driver evict and restore the process's queues, a 60-70 ms stall of whatever HIP call comes next (found as config
+// 4's "slow first repetition").  Below the threshold: hipMemcpyAsync, which the runtime stages itself;
+// for device -> host the caller synchronises the stream as before.
+int copy_h2d(void* dev, const void* host, size_t bytes, hipStream_t s);
+int copy_d2h(void* host, const void* dev, size_t bytes, hipStream_t s);
+// the same for `cols` columns of `rowbytes` bytes each with a pitch on either side
+int copy_h2d_2d(void* dev, size_t dpitch, const void* host, size_t hpitch, size_t rowbytes, size_t cols, hipStream_t s);
+int copy_d2h_2d(void* host, size_t hpitch, const void* dev, size_t dpitch, size_t rowbytes, size_t cols, hipStream_t s);
+
 // host (ldh) <-> device (padded ld) copies of a column-major matrix
 int upload_matrix(DevMat& dst, const double* host, int rows, int cols, int ldh, hipStream_t s);
 int download_matrix(double* host, int ldh, const double* dev, int ldd, int rows, int cols,

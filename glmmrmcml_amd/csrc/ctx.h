@@ -19,7 +19,21 @@ typedef int (*reduce_fn)(void* user, double* dev_buf, int n);
 // kernel family that served an HMC product (glmmr_mcml_ctx_last_kernels)
 enum { KERNEL_SKINNY = 0, KERNEL_BAND = 1, KERNEL_DLDS = 2, KERNEL_REG = 3, KERNEL_SPARSE = 4 };
 
+// the sampler's step-count read-back (hmc.hip hmc_sample): a ring of host memory mapped into the device, written by
+// k_max_steps with (proposal sequence number << 32 | count), read by the host with plain loads; lives as long as the context
+struct StepRing {
+    static constexpr int SLOTS = 8;
+    unsigned long long* h = nullptr;    // host address
+    unsigned long long* d = nullptr;    // the same memory as the device sees it
+    unsigned seq = 0;                   // sequence number of the last proposal launched
+    StepRing() = default;
+    StepRing(const StepRing&) = delete;
+    StepRing& operator=(const StepRing&) = delete;
+    ~StepRing() { if (h) (void)hipHostFree(h); }
+};
+
 struct HmcState {
+    StepRing ring;
     int C = 0;                  // chains resident
     int Cw = 0;                 // columns the two products and the log-density kernels process (= C; the No-U-Turn
                                 // sampler packs the chains whose trees still grow into the first Cw columns)

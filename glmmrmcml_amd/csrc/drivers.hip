@@ -471,3 +471,13 @@ int drv_full(Ctx& c, const double* start, int nstart, int mcnr, int m, int maxit
 }
 
 }  // namespace mcml
+
+extern "C" int glmmr_mcml_dbg_phase_ms(int enable, int reset, double* out8)
+{
+    mcml::PhaseClock& pc = mcml::phase_clock();
+    std::lock_guard<std::mutex> g(pc.mu);
+    if (out8) for (int i = 0; i < 4; ++i) { out8[i] = pc.ms[i]; out8[4 + i] = (double)pc.n[i]; }
+    if (reset) for (int i = 0; i < 4; ++i) { pc.ms[i] = 0; pc.n[i] = 0; }
+    pc.on.store(enable != 0, std::memory_order_relaxed);
+    return 0;
+}

@@ -14,6 +14,7 @@
 // log_prob(u) and log_grad(u) of the current state are cached from the step that
 // produced it instead of being recomputed (the reference recomputes them,
 // :64,82): same numbers, 2*steps GEMMs per proposal instead of 2*steps + 4.
+#include <chrono>
 #include "../../include/glmmr_mcml_c.h"
 #include "ctx.h"
 #include "dgemm_mfma.h"
@@ -318,7 +319,9 @@ __global__ __launch_bounds__(256) void k_hmc_propose(const double* V, const doub
     }
 }
 
-__global__ void k_max_steps(const int* steps, int C, int* out)
+// slot (nullable): host memory mapped into the device -- the count goes there too, tagged with the proposal's sequence number,
+// as one 64-bit system-scope store (hmc_sample reads it back with plain loads)
+__global__ void k_max_steps(const int* steps, int C, int* out, unsigned long long* slot = nullptr, unsigned seq = 0)
 {
     __shared__ int sh[256];
     int v = 0;
@@ -326,7 +329,10 @@ __global__ void k_max_steps(const int* steps, int C, int* out)
     sh[threadIdx.x] = v;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] = max(sh[threadIdx.x], sh[threadIdx.x + o]); __syncthreads(); }
-    if (threadIdx.x == 0) out[0] = sh[0];
+    if (threadIdx.x == 0) {
+        out[0] = sh[0];
+        if (slot) __hip_atomic_store(slot, ((unsigned long long)seq << 32) | (unsigned)sh[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // new_proposal, second part (mhmcmc.h:80-117)
@@ -680,6 +686,11 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
     const int ncols = (C == 1) ? d + 1 : C * d;                   // mhmcmc.h:126: Q x (nsamp+1)
     const int Q = c.Q, n = c.n;
     HmcState& h = c.hmc;
+    // GLMMR_MCML_HMC_TIMING=1: host wall-clock of this call's segments on stderr (set-up | proposals | tail), and of the slowest
+    // proposal's enqueue -- to tell a slow call's cause from outside (run-to-run jitter)
+    static const bool timing = getenv("GLMMR_MCML_HMC_TIMING") != nullptr;
+    const auto tc0 = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     MCML_TRY(model_update_beta(c, beta));
     MCML_TRY(hmc_alloc(c, C));
     ChainArrays ca = chain_arrays(h);
@@ -691,12 +702,12 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
     const double* p_init = nullptr; const double* p_mom = nullptr;
     if (inj_init) {
         MCML_TRY(d_init.ensure(sizeof(double) * (size_t)Q * C));
-        MCML_HIP(hipMemcpyAsync(d_init.p, inj_init, sizeof(double) * (size_t)Q * C, hipMemcpyHostToDevice, c.stream));
+        MCML_TRY(copy_h2d(d_init.p, inj_init, sizeof(double) * (size_t)Q * C, c.stream));
         p_init = d_init.d();
     }
     if (inj_mom) {
         MCML_TRY(d_mom.ensure(sizeof(double) * (size_t)Q * C * total));
-        MCML_HIP(hipMemcpyAsync(d_mom.p, inj_mom, sizeof(double) * (size_t)Q * C * total, hipMemcpyHostToDevice, c.stream));
+        MCML_TRY(copy_h2d(d_mom.p, inj_mom, sizeof(double) * (size_t)Q * C * total, c.stream));
         p_mom = d_mom.d();
     }
     if (flags_out) MCML_TRY(d_flags.ensure((size_t)C * total));
@@ -725,24 +736,45 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
     // value.  Reading it back costs a host synchronisation per proposal (~50 us of idle GPU).  While
     // the step counts observed so far sit at the cap (lambda / e >= max_steps, the usual regime), the
     // cap itself is launched without waiting -- iterations beyond a chain's own count are masked
-    // no-ops, so results are identical -- and the true value is read back asynchronously (pinned
-    // ring, 4 proposals deep); an observation below the cap switches back to the exact, synchronous
-    // path.  GLMMR_MCML_HMC_SPEC=0 disables the speculation.
+    // no-ops, so results are identical -- and the true value comes back on its own: k_max_steps stores
+    // (proposal sequence number, count) into a ring of host memory mapped into the device (StepRing,
+    // ctx.h), which the host reads with plain loads; an observation below the cap switches back to the
+    // exact, synchronous path.  GLMMR_MCML_HMC_SPEC=0 disables the speculation.
+    // (Until round 3 the read-back was a hipMemcpyAsync into a pinned ring allocated per call plus an
+    // event per slot: in about one process in four ONE such enqueue stalled for 65-70 ms inside the
+    // runtime -- config 4's "slow first repetition", DESIGN.md 6 -- and every call paid a hipHostMalloc,
+    // four event creations and their release.  The loop now makes no HIP call besides kernel launches
+    // and, on the synchronous path, the stream synchronisation.)
     static const bool spec_allowed = !(getenv("GLMMR_MCML_HMC_SPEC") && atoi(getenv("GLMMR_MCML_HMC_SPEC")) == 0);
-    constexpr int RING = 4;
-    int* h_ring = nullptr;
-    hipEvent_t ring_ev[RING];
-    bool ring_busy[RING] = {false, false, false, false};
-    MCML_HIP(hipHostMalloc((void**)&h_ring, sizeof(int) * RING));
-    for (int i = 0; i < RING; ++i) MCML_HIP(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming));
-    struct RingGuard {
-        int* p; hipEvent_t* ev; int n; hipStream_t s;
-        ~RingGuard() { (void)hipStreamSynchronize(s); for (int i = 0; i < n; ++i) (void)hipEventDestroy(ev[i]); (void)hipHostFree(p); }
-    } ring_guard{h_ring, ring_ev, RING, c.stream};
+    constexpr int RING = StepRing::SLOTS, AHEAD = 4;      // the host runs at most AHEAD proposals ahead of the last count it has seen
+    StepRing& ring = h.ring;
+    if (!ring.h) {
+        MCML_HIP(hipHostMalloc((void**)&ring.h, sizeof(unsigned long long) * RING, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(ring.h, 0, sizeof(unsigned long long) * RING);
+        MCML_HIP(hipHostGetDevicePointer((void**)&ring.d, ring.h, 0));
+    }
     int seen_maxs = -1;                         // latest step count actually observed
+    const unsigned seq0 = ring.seq + 1;          // sequence number of this call's first proposal
+    unsigned seen_seq = seq0 - 1;                // newest proposal of this call whose count has arrived
+    auto harvest = [&]() {                       // newest token of this call in the ring -> seen_seq, seen_maxs
+        for (int i = 0; i < RING; ++i) {
+            const unsigned long long tok = __atomic_load_n(ring.h + i, __ATOMIC_ACQUIRE);
+            const unsigned sq = (unsigned)(tok >> 32);
+            if ((int)(sq - seq0) >= 0 && (int)(sq - seen_seq) > 0) { seen_seq = sq; seen_maxs = (int)(unsigned)tok; }
+        }
+    };
     bool pending_commit = false;                // sparse operator: the last decisions are applied by the next k_cm_propose
     const bool lf = h.cm && cm_lfuse(c);        // factored operator: the backward pass of step s leaves LX for step s + 1
+    const double t_setup = since(tc0);
+    const auto tc1 = std::chrono::steady_clock::now();
+    auto tp_prev = tc1;
+    double t_sync = 0, t_slowest = 0; int n_sync = 0;
+    double seg[5] = {0, 0, 0, 0, 0};   // slowest: propose launches | read-back enqueue (speculative) | read-back enqueue (synchronous) | trajectory launches | accept, commit, store
+    auto mark = [&](int k, std::chrono::steady_clock::time_point t) { if (timing) { const double d = since(t); if (d > seg[k]) seg[k] = d; } };
     for (int it = 0; it < total; ++it) {
+        const auto tp0 = std::chrono::steady_clock::now();
+        if (it > 0 && timing) { const double d = since(tp_prev); if (d > t_slowest) t_slowest = d; }
+        tp_prev = tp0;
         if (h.cm) {
             const CmParts p = cm_parts(c);
             hipLaunchKernelGGL(k_cm_propose, dim3((C + 63) / 64, p.nchq), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(),
@@ -755,28 +787,42 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         hipLaunchKernelGGL(k_hmc_propose, dim3(C), dim3(256), 0, c.stream, h.V.d(), h.GRAD.d(), h.R.d(), h.UP.d(),
                            h.V.ld, Q, ca, o->lambda, o->max_steps, seed, (uint32_t)o->chain_offset, iter_idx, it,
                            p_mom, C);
-        hipLaunchKernelGGL(k_max_steps, dim3(1), dim3(256), 0, c.stream, ca.steps, C, d_maxs);
+        const unsigned seq = ++ring.seq;
+        const int slot = (int)(seq % RING);
+        hipLaunchKernelGGL(k_max_steps, dim3(1), dim3(256), 0, c.stream, ca.steps, C, d_maxs, ring.d + slot, seq);
         MCML_HIP(hipGetLastError());
-        for (int i = 0; i < RING; ++i)          // harvest finished read-backs
-            if (ring_busy[i] && hipEventQuery(ring_ev[i]) == hipSuccess) { seen_maxs = h_ring[i]; ring_busy[i] = false; }
+        mark(0, tp0);
+        const auto tq0 = std::chrono::steady_clock::now();
+        harvest();
         int maxs = 0;
-        if (spec_allowed && seen_maxs == o->max_steps) {
-            const int slot = it % RING;
-            if (ring_busy[slot]) { MCML_HIP(hipEventSynchronize(ring_ev[slot])); seen_maxs = h_ring[slot]; ring_busy[slot] = false; }
-            MCML_HIP(hipMemcpyAsync(h_ring + slot, d_maxs, sizeof(int), hipMemcpyDeviceToHost, c.stream));
-            MCML_HIP(hipEventRecord(ring_ev[slot], c.stream));
-            ring_busy[slot] = true;
+        bool spec = spec_allowed && seen_maxs == o->max_steps;
+        if (spec) {
+            // bounded look-ahead: a count below the cap must be noticed within AHEAD proposals (in the dense path a masked
+            // step is a full product).  Plain loads of host memory; a count that does not arrive falls back to the wait below
+            const auto tw0 = std::chrono::steady_clock::now();
+            while ((int)(seq - seen_seq) > AHEAD) {
+                harvest();
+                if ((int)(seq - seen_seq) > AHEAD && since(tw0) > 2000.0) { spec = false; break; }
+            }
+            if (spec && seen_maxs != o->max_steps) spec = false;
+        }
+        if (spec) {
             maxs = o->max_steps;
+            mark(1, tq0);
         } else {
-            MCML_HIP(hipMemcpyAsync(&maxs, d_maxs, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+            const auto ts0 = std::chrono::steady_clock::now();
             MCML_HIP(hipStreamSynchronize(c.stream));
-            for (int i = 0; i < RING; ++i) ring_busy[i] = false;     // everything older has completed
-            seen_maxs = maxs;
+            if (timing) { t_sync += since(ts0); ++n_sync; }
+            const unsigned long long tok = __atomic_load_n(ring.h + slot, __ATOMIC_ACQUIRE);
+            MCML_REQUIRE((unsigned)(tok >> 32) == seq, "hmc: the step count of proposal %d did not arrive (token %llx, expected sequence %u)", it, tok, seq);
+            maxs = (int)(unsigned)tok;
+            seen_maxs = maxs; seen_seq = seq;
         }
         MCML_REQUIRE(maxs >= 1 && maxs <= o->max_steps, "hmc: step count %d out of range", maxs);
         // kernel timing (bench.py's roofline): every marker between two dependent launches costs ~2.5 us of idle GPU,
         // so one proposal in four is timed -- still hundreds of launches per MCML iteration behind the average
         c.prof.skip = (it & 3) != 0;
+        const auto tt0 = std::chrono::steady_clock::now();
         int rc_traj = MCML_OK;
         for (int s = 0; s < maxs && rc_traj == MCML_OK; ++s) {
             const bool fuse = h.cm && cm_fuse();
@@ -784,6 +830,8 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
             if (rc_traj == MCML_OK) rc_traj = hmc_backward(c, h.UP.d(), h.GRADP.d(), s, var_par, 1, true, lf && s + 1 < maxs);
         }
         c.prof.skip = false;
+        mark(3, tt0);
+        const auto ta0 = std::chrono::steady_clock::now();
         MCML_TRY(rc_traj);
         c.prof.unchain();
         const int adapt = (it < o->warmup) && (it < o->adapt);     // mhmcmc.h:131-136
@@ -813,7 +861,10 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         } else if (it >= o->warmup) { col = it - o->warmup; stride = d; }
         if (col >= 0) store(stride, col);
         MCML_HIP(hipGetLastError());
+        mark(4, ta0);
     }
+    const double t_loop = since(tc1);
+    const auto tc2 = std::chrono::steady_clock::now();
     // return (L * samples)  (mhmcmc.h:155)
     MCML_TRY(c.U.alloc(Q, ncols));
     MCML_HIP(hipMemsetAsync(c.U.d(), 0, sizeof(double) * (size_t)c.U.ld * ncols, c.stream));
@@ -829,12 +880,15 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
     c.mcols = ncols;
     c.niter = (C == 1) ? d : ncols;                                // mcmlmodel.h:73 vs mhmcmc.h:126 (D5)
     c.zu_valid = false; c.uall_valid = false;
-    if (flags_out) MCML_HIP(hipMemcpyAsync(flags_out, d_flags.p, (size_t)C * total, hipMemcpyDeviceToHost, c.stream));
-    if (probs_out) MCML_HIP(hipMemcpyAsync(probs_out, d_probs.p, sizeof(double) * (size_t)C * total, hipMemcpyDeviceToHost, c.stream));
+    if (flags_out) MCML_TRY(copy_d2h(flags_out, d_flags.p, (size_t)C * total, c.stream));
+    if (probs_out) MCML_TRY(copy_d2h(probs_out, d_probs.p, sizeof(double) * (size_t)C * total, c.stream));
     double dg[6] = {0, 0, 0, 0, 0, 0};
     hipLaunchKernelGGL(k_hmc_diag, dim3(1), dim3(64), 0, c.stream, ca, C, c.scalars.d() + 8);
-    MCML_HIP(hipMemcpyAsync(dg, c.scalars.d() + 8, sizeof dg, hipMemcpyDeviceToHost, c.stream));
+    MCML_TRY(copy_d2h(dg, c.scalars.d() + 8, sizeof dg, c.stream));
     MCML_HIP(hipStreamSynchronize(c.stream));
+    if (timing)
+        fprintf(stderr, "hmc_sample: set-up %.2f ms | %d proposals %.2f ms enqueue (%d synchronous, %.2f ms waiting; slowest proposal %.2f ms: propose %.2f, read-back spec %.2f / sync %.2f, trajectory %.2f, accept %.2f) | tail %.2f ms\n",
+                t_setup, total, t_loop, n_sync, t_sync, t_slowest, seg[0], seg[1], seg[2], seg[3], seg[4], since(tc2));
     c.prof.collect();
     if (diag) {
         diag->accept_rate = dg[0] / ((double)C * total);
@@ -857,8 +911,7 @@ int hmc_dbg_log_prob_grad(Ctx& c, const double* beta, double var_par, const doub
     if (h.cm) {
         DevMat tmp;                                   // Q x ncols column-major staging
         MCML_TRY(tmp.alloc(c.Q, ncols));
-        MCML_HIP(hipMemcpy2DAsync(tmp.d(), sizeof(double) * tmp.ld, V, sizeof(double) * c.Q, sizeof(double) * c.Q,
-                                  ncols, hipMemcpyHostToDevice, c.stream));
+        MCML_TRY(copy_h2d_2d(tmp.d(), sizeof(double) * tmp.ld, V, sizeof(double) * c.Q, sizeof(double) * c.Q, ncols, c.stream));
         // V[c + q * ldc] = tmp[q + c * ld]
         hipLaunchKernelGGL(k_cm_transpose, dim3((ncols + 31) / 32, (c.Q + 31) / 32), dim3(256), 0, c.stream, tmp.d(), tmp.ld,
                            ncols, c.Q, h.V.d(), (size_t)h.V.ld, (size_t)1, 0);
@@ -867,14 +920,13 @@ int hmc_dbg_log_prob_grad(Ctx& c, const double* beta, double var_par, const doub
         hipLaunchKernelGGL(k_cm_transpose, dim3((c.Q + 31) / 32, (ncols + 31) / 32), dim3(256), 0, c.stream, h.GRAD.d(), h.GRAD.ld,
                            c.Q, ncols, tmp.d(), (size_t)tmp.ld, (size_t)1, 0);
         MCML_HIP(hipGetLastError());
-        MCML_HIP(hipMemcpyAsync(lp, ca.lpcur, sizeof(double) * ncols, hipMemcpyDeviceToHost, c.stream));
+        MCML_TRY(copy_d2h(lp, ca.lpcur, sizeof(double) * ncols, c.stream));
         MCML_TRY(download_matrix(G, c.Q, tmp.d(), tmp.ld, c.Q, ncols, c.stream));
         return c.sync();                              // tmp goes out of scope
     }
-    MCML_HIP(hipMemcpy2DAsync(h.V.d(), sizeof(double) * h.V.ld, V, sizeof(double) * c.Q, sizeof(double) * c.Q,
-                              ncols, hipMemcpyHostToDevice, c.stream));
+    MCML_TRY(copy_h2d_2d(h.V.d(), sizeof(double) * h.V.ld, V, sizeof(double) * c.Q, sizeof(double) * c.Q, ncols, c.stream));
     MCML_TRY(hmc_eval_state(c, var_par));
-    MCML_HIP(hipMemcpyAsync(lp, ca.lpcur, sizeof(double) * ncols, hipMemcpyDeviceToHost, c.stream));
+    MCML_TRY(copy_d2h(lp, ca.lpcur, sizeof(double) * ncols, c.stream));
     return download_matrix(G, c.Q, h.GRAD.d(), h.GRAD.ld, c.Q, ncols, c.stream);
 }
 

@@ -239,12 +239,12 @@ struct LaFit {
     int set_v(const double* host_v)
     {
         hv.assign(host_v, host_v + Q);
-        MCML_HIP(hipMemcpyAsync(v.p, hv.data(), sizeof(double) * (size_t)Q, hipMemcpyHostToDevice, c.stream));
+        MCML_TRY(copy_h2d(v.p, hv.data(), sizeof(double) * (size_t)Q, c.stream));
         return MCML_OK;
     }
     int get_v()
     {
-        MCML_HIP(hipMemcpyAsync(hv.data(), v.p, sizeof(double) * (size_t)Q, hipMemcpyDeviceToHost, c.stream));
+        MCML_TRY(copy_d2h(hv.data(), v.p, sizeof(double) * (size_t)Q, c.stream));
         MCML_HIP(hipStreamSynchronize(c.stream));
         return MCML_OK;
     }
@@ -264,7 +264,7 @@ struct LaFit {
     }
     int scalar_from(const double* dev, double* host)
     {
-        MCML_HIP(hipMemcpyAsync(host, dev, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        MCML_TRY(copy_d2h(host, dev, sizeof(double), c.stream));
         MCML_HIP(hipStreamSynchronize(c.stream));
         return MCML_OK;
     }
@@ -294,7 +294,7 @@ struct LaFit {
         hipLaunchKernelGGL(k_la_sum, dim3(1), dim3(256), 0, c.stream, part.d(), qb, small.d() + 1);
         MCML_HIP(hipGetLastError());
         double h[2];
-        MCML_HIP(hipMemcpyAsync(h, small.p, sizeof(double) * 2, hipMemcpyDeviceToHost, c.stream));
+        MCML_TRY(copy_d2h(h, small.p, sizeof(double) * 2, c.stream));
         MCML_HIP(hipStreamSynchronize(c.stream));
         *ll = h[0]; *vv = h[1];
         return MCML_OK;
@@ -436,8 +436,8 @@ struct LaFit {
         hipLaunchKernelGGL(k_la_xtwx, dim3(P * P + P), dim3(256), 0, c.stream, c.X.d(), c.X.ld, n, P, W.d(), tmpn3.d(), small.d());
         MCML_HIP(hipGetLastError());
         std::vector<double> st((size_t)P * P + P), resid(n);
-        MCML_HIP(hipMemcpyAsync(st.data(), small.p, sizeof(double) * st.size(), hipMemcpyDeviceToHost, c.stream));
-        MCML_HIP(hipMemcpyAsync(resid.data(), tmpn2.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c.stream));
+        MCML_TRY(copy_d2h(st.data(), small.p, sizeof(double) * st.size(), c.stream));
+        MCML_TRY(copy_d2h(resid.data(), tmpn2.p, sizeof(double) * (size_t)n, c.stream));
         // vgrad = -D0 v + post * ZL' score
         hipLaunchKernelGGL(k_la_gemv_t, dim3((Q + 3) / 4), dim3(256), 0, c.stream, c.ZL.d(), c.ZL.ld, n, Q, tmpn.d(), tmpq.d(),
                            glm_score_post(var_par, flink), 0.0);
@@ -545,7 +545,7 @@ struct LaFit {
             MCML_TRY(ensure_model_L());
             hipLaunchKernelGGL(k_la_gemv_n, dim3((Q + 255) / 256), dim3(256), 0, c.stream, c.L.d(), c.L.ld, Q, Q, v.d(), tmpq.d());
             MCML_HIP(hipGetLastError());
-            MCML_HIP(hipMemcpyAsync(u_out, tmpq.p, sizeof(double) * (size_t)Q, hipMemcpyDeviceToHost, c.stream));
+            MCML_TRY(copy_d2h(u_out, tmpq.p, sizeof(double) * (size_t)Q, c.stream));
             MCML_HIP(hipStreamSynchronize(c.stream));
         }
         if (converged_out) *converged_out = converged ? 1 : 0;

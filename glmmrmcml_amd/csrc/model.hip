@@ -30,7 +30,7 @@ int model_setup(Ctx& c, const double* Z, const double* X, const double* y)
     std::vector<double> yy(y, y + n);
     if (c.flink == 8)                      // mcmlmodel.h:90-92: y_ = y_.log()
         for (auto& v : yy) v = log(v);
-    MCML_HIP(hipMemcpyAsync(c.y.p, yy.data(), sizeof(double) * n, hipMemcpyHostToDevice, c.stream));
+    MCML_TRY(copy_h2d(c.y.p, yy.data(), sizeof(double) * n, c.stream));
     // sparse rows of Z (indicator designs): padded CSR, width = max nnz per row
     size_t nnz = 0; int maxrow = 0;
     std::vector<int> cnt(n, 0);
@@ -52,8 +52,8 @@ int model_setup(Ctx& c, const double* Z, const double* X, const double* y)
         c.h_zidx = zi; c.h_zval = zv;
         MCML_TRY(c.z_idx.ensure(sizeof(int) * zi.size()));
         MCML_TRY(c.z_val.ensure(sizeof(double) * zv.size()));
-        MCML_HIP(hipMemcpyAsync(c.z_idx.p, zi.data(), sizeof(int) * zi.size(), hipMemcpyHostToDevice, c.stream));
-        MCML_HIP(hipMemcpyAsync(c.z_val.p, zv.data(), sizeof(double) * zv.size(), hipMemcpyHostToDevice, c.stream));
+        MCML_TRY(copy_h2d(c.z_idx.p, zi.data(), sizeof(int) * zi.size(), c.stream));
+        MCML_TRY(copy_h2d(c.z_val.p, zv.data(), sizeof(double) * zv.size(), c.stream));
         MCML_HIP(hipStreamSynchronize(c.stream));
     }
     MCML_HIP(hipStreamSynchronize(c.stream));
@@ -75,7 +75,7 @@ int model_update_beta(Ctx& c, const double* beta)
     MCML_REQUIRE(c.n > 0, "no model in this context");
     MCML_TRY(c.scratch.ensure(sizeof(double) * 64));
     MCML_REQUIRE(c.P <= 64, "P > 64 fixed effects");
-    MCML_HIP(hipMemcpyAsync(c.scratch.p, beta, sizeof(double) * c.P, hipMemcpyHostToDevice, c.stream));
+    MCML_TRY(copy_h2d(c.scratch.p, beta, sizeof(double) * c.P, c.stream));
     hipLaunchKernelGGL(k_xb, dim3((c.n + 255) / 256), dim3(256), 0, c.stream, c.X.d(), c.X.ld, c.n, c.P,
                        c.scratch.d(), c.xb.d());
     MCML_HIP(hipGetLastError());
@@ -194,14 +194,14 @@ static int sparse_zl_setup(Ctx& c)
     MCML_TRY(sp.ell_z.ensure(sizeof(double) * tot)); MCML_TRY(sp.ell_val.ensure(sizeof(double) * tot));
     MCML_TRY(sp.csr_ptr.ensure(sizeof(int) * (size_t)(Q + 1))); MCML_TRY(sp.csr_i.ensure(sizeof(int) * (size_t)(nnz + 1)));
     MCML_TRY(sp.csr_pos.ensure(sizeof(int) * (size_t)(nnz + 1)));
-    MCML_HIP(hipMemcpyAsync(sp.ell_col.p, col.data(), sizeof(int) * tot, hipMemcpyHostToDevice, c.stream));
-    MCML_HIP(hipMemcpyAsync(sp.ell_src.p, src.data(), sizeof(int) * tot, hipMemcpyHostToDevice, c.stream));
-    MCML_HIP(hipMemcpyAsync(sp.ell_z.p, zz.data(), sizeof(double) * tot, hipMemcpyHostToDevice, c.stream));
-    MCML_HIP(hipMemcpyAsync(sp.csr_ptr.p, ptr.data(), sizeof(int) * (size_t)(Q + 1), hipMemcpyHostToDevice, c.stream));
-    MCML_HIP(hipMemcpyAsync(sp.csr_i.p, ci.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c.stream));
-    MCML_HIP(hipMemcpyAsync(sp.csr_pos.p, cp.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, c.stream));
+    MCML_TRY(copy_h2d(sp.ell_col.p, col.data(), sizeof(int) * tot, c.stream));
+    MCML_TRY(copy_h2d(sp.ell_src.p, src.data(), sizeof(int) * tot, c.stream));
+    MCML_TRY(copy_h2d(sp.ell_z.p, zz.data(), sizeof(double) * tot, c.stream));
+    MCML_TRY(copy_h2d(sp.csr_ptr.p, ptr.data(), sizeof(int) * (size_t)(Q + 1), c.stream));
+    MCML_TRY(copy_h2d(sp.csr_i.p, ci.data(), sizeof(int) * (size_t)nnz, c.stream));
+    MCML_TRY(copy_h2d(sp.csr_pos.p, cp.data(), sizeof(int) * (size_t)nnz, c.stream));
     MCML_TRY(sp.row_start.ensure(sizeof(int) * (size_t)Q));
-    MCML_HIP(hipMemcpyAsync(sp.row_start.p, start_of.data(), sizeof(int) * (size_t)Q, hipMemcpyHostToDevice, c.stream));
+    MCML_TRY(copy_h2d(sp.row_start.p, start_of.data(), sizeof(int) * (size_t)Q, c.stream));
     // the factored form: rows of Z' (CSR) and the end of each column of L
     {
         std::vector<int> zcnt(Q, 0), end_of(Q);
@@ -226,10 +226,10 @@ static int sparse_zl_setup(Ctx& c)
             }
         MCML_TRY(sp.zcsr_ptr.ensure(sizeof(int) * (size_t)(Q + 1))); MCML_TRY(sp.zcsr_i.ensure(sizeof(int) * (size_t)(nz + 1)));
         MCML_TRY(sp.zcsr_val.ensure(sizeof(double) * (size_t)(nz + 1))); MCML_TRY(sp.row_end.ensure(sizeof(int) * (size_t)Q));
-        MCML_HIP(hipMemcpyAsync(sp.zcsr_ptr.p, zptr.data(), sizeof(int) * (size_t)(Q + 1), hipMemcpyHostToDevice, c.stream));
-        MCML_HIP(hipMemcpyAsync(sp.zcsr_i.p, zi.data(), sizeof(int) * (size_t)nz, hipMemcpyHostToDevice, c.stream));
-        MCML_HIP(hipMemcpyAsync(sp.zcsr_val.p, zv.data(), sizeof(double) * (size_t)nz, hipMemcpyHostToDevice, c.stream));
-        MCML_HIP(hipMemcpyAsync(sp.row_end.p, end_of.data(), sizeof(int) * (size_t)Q, hipMemcpyHostToDevice, c.stream));
+        MCML_TRY(copy_h2d(sp.zcsr_ptr.p, zptr.data(), sizeof(int) * (size_t)(Q + 1), c.stream));
+        MCML_TRY(copy_h2d(sp.zcsr_i.p, zi.data(), sizeof(int) * (size_t)nz, c.stream));
+        MCML_TRY(copy_h2d(sp.zcsr_val.p, zv.data(), sizeof(double) * (size_t)nz, c.stream));
+        MCML_TRY(copy_h2d(sp.row_end.p, end_of.data(), sizeof(int) * (size_t)Q, c.stream));
         sp.nnz_z = nz; sp.nnz_l = nl;
         // the blocks in row order, for the kernel that takes a whole block per wave (contiguous and covering 0 .. Q, or not used)
         {
@@ -305,7 +305,7 @@ int model_update_L(Ctx& c)
             hipLaunchKernelGGL(k_band_ranges, dim3(nb), dim3(256), 0, c.stream, A.d(), A.ld, M, K, c.kr_scratch.as<int>());
             MCML_HIP(hipGetLastError());
             std::vector<int> h(2 * (size_t)nb);
-            MCML_HIP(hipMemcpyAsync(h.data(), c.kr_scratch.p, sizeof(int) * h.size(), hipMemcpyDeviceToHost, c.stream));
+            MCML_TRY(copy_d2h(h.data(), c.kr_scratch.p, sizeof(int) * h.size(), c.stream));
             MCML_HIP(hipStreamSynchronize(c.stream));
             // the K-tile ranges of a triangular ZL do not change from one MCML iteration to the next: keep the device
             // plans (work lists, partial-tile buffers) unless they did
@@ -351,7 +351,7 @@ int model_loglik_sum(Ctx& c, double var_par, double* sum_out)
                        c.xb.d(), c.y.d(), var_par, c.flink, c.partials.d());
     MCML_HIP(hipGetLastError());
     MCML_TRY(device_sum(c, c.partials.d(), gx * gy, c.scalars.d() + 4));
-    MCML_HIP(hipMemcpyAsync(sum_out, c.scalars.d() + 4, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    MCML_TRY(copy_d2h(sum_out, c.scalars.d() + 4, sizeof(double), c.stream));
     MCML_HIP(hipStreamSynchronize(c.stream));
     return MCML_OK;
 }
@@ -487,7 +487,7 @@ int model_mcnr_stats(Ctx& c, double var_par, double* stats)
                        c.reduce_buf.d());
     MCML_HIP(hipGetLastError());
     MCML_TRY(allreduce_dev(c, c.reduce_buf.d(), ns));              // RCCL all-reduce of the statistics (comm.hip)
-    MCML_HIP(hipMemcpyAsync(stats, c.reduce_buf.p, sizeof(double) * ns, hipMemcpyDeviceToHost, c.stream));
+    MCML_TRY(copy_d2h(stats, c.reduce_buf.p, sizeof(double) * ns, c.stream));
     MCML_HIP(hipStreamSynchronize(c.stream));
     return MCML_OK;
 }

@@ -508,11 +508,11 @@ int potrf_leaf_profile(Ctx& c, unsigned long long* host10)
     MCML_TRY(c.linv.ensure(sizeof(double) * 2 * CHOL_NB * CHOL_NB));
     std::vector<double> h((size_t)A.ld * 128, 0.0);
     for (int j = 0; j < 128; ++j) for (int i = 0; i < 128; ++i) h[i + (size_t)j * A.ld] = (i == j ? 130.0 : 1.0 / (1 + abs(i - j)));
-    MCML_HIP(hipMemcpy(A.d(), h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    MCML_TRY(copy_h2d(A.d(), h.data(), sizeof(double) * h.size(), 0)); MCML_HIP(hipDeviceSynchronize());
     MCML_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_potrf_leaf), (int)(sizeof(double) * (128 * 129 + 128 + 7 * 256 + 64))));
     MCML_HIP(hipMemset(c.linv.p, 0, sizeof(double) * 2 * CHOL_NB * CHOL_NB));
     for (int rep = 0; rep < 3; ++rep) {
-        MCML_HIP(hipMemcpy(A.d(), h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+        MCML_TRY(copy_h2d(A.d(), h.data(), sizeof(double) * h.size(), 0)); MCML_HIP(hipDeviceSynchronize());
         hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(LEAF_NT), sizeof(double) * (128 * 129 + 128 + 7 * 256 + 64), c.stream, A.d(), A.ld,
                            128, c.linv.d(), c.scalars.as<int>() + 32, prof.as<unsigned long long>());
         MCML_HIP(hipStreamSynchronize(c.stream));
@@ -1075,12 +1075,12 @@ int mvn_setup(Ctx& c)
 {
     const CovSpec& cs = c.cov;
     MCML_TRY(c.d_cov.ensure(sizeof(int32_t) * cs.cov.size()));
-    MCML_HIP(hipMemcpyAsync(c.d_cov.p, cs.cov.data(), sizeof(int32_t) * cs.cov.size(), hipMemcpyHostToDevice, c.stream));
+    MCML_TRY(copy_h2d(c.d_cov.p, cs.cov.data(), sizeof(int32_t) * cs.cov.size(), c.stream));
     MCML_TRY(c.d_data.ensure(sizeof(double) * (cs.data.size() + 1)));
     if (!cs.data.empty())
-        MCML_HIP(hipMemcpyAsync(c.d_data.p, cs.data.data(), sizeof(double) * cs.data.size(), hipMemcpyHostToDevice, c.stream));
+        MCML_TRY(copy_h2d(c.d_data.p, cs.data.data(), sizeof(double) * cs.data.size(), c.stream));
     MCML_TRY(c.d_blocks.ensure(sizeof(CovBlock) * cs.blocks.size()));
-    MCML_HIP(hipMemcpyAsync(c.d_blocks.p, cs.blocks.data(), sizeof(CovBlock) * cs.blocks.size(), hipMemcpyHostToDevice, c.stream));
+    MCML_TRY(copy_h2d(c.d_blocks.p, cs.blocks.data(), sizeof(CovBlock) * cs.blocks.size(), c.stream));
     std::vector<int> rowblock(cs.N, -1), small;
     c.maxdim_large = 0; c.n_small = 0; c.n_diag_rows = 0;
     for (int b = 0; b < cs.B; ++b) {
@@ -1096,12 +1096,12 @@ int mvn_setup(Ctx& c)
         }
     }
     MCML_TRY(c.d_rowblock.ensure(sizeof(int) * (size_t)(cs.N + 1)));
-    MCML_HIP(hipMemcpyAsync(c.d_rowblock.p, rowblock.data(), sizeof(int) * cs.N, hipMemcpyHostToDevice, c.stream));
+    MCML_TRY(copy_h2d(c.d_rowblock.p, rowblock.data(), sizeof(int) * cs.N, c.stream));
     MCML_TRY(c.scalars.ensure(sizeof(double) * 64));
     MCML_HIP(hipMemsetAsync(c.scalars.p, 0, sizeof(double) * 64, c.stream));
     if (c.n_small) {
         MCML_TRY(c.small_ids.ensure(sizeof(int) * small.size()));
-        MCML_HIP(hipMemcpyAsync(c.small_ids.p, small.data(), sizeof(int) * small.size(), hipMemcpyHostToDevice, c.stream));
+        MCML_TRY(copy_h2d(c.small_ids.p, small.data(), sizeof(int) * small.size(), c.stream));
     }
     if (c.maxdim_large) {
         MCML_TRY(c.Dwork.alloc(c.maxdim_large, c.maxdim_large));
@@ -1125,7 +1125,7 @@ static int theta_arg(const Ctx& c, const double* theta, ThetaArg& th)
 static int check_errflag(Ctx& c, const char* what)
 {
     int flag = 0;
-    MCML_HIP(hipMemcpyAsync(&flag, c.scalars.as<int>() + 32, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    MCML_TRY(copy_d2h(&flag, c.scalars.as<int>() + 32, sizeof(int), c.stream));
     MCML_HIP(hipStreamSynchronize(c.stream));
     if (flag) {
         MCML_HIP(hipMemsetAsync(c.scalars.as<int>() + 32, 0, sizeof(int), c.stream));
@@ -1153,7 +1153,7 @@ static int mvn_loglik_enqueue(Ctx& c, const double* theta, const double* Us, int
 int mvn_loglik_sum_on(Ctx& c, const double* theta, const double* Us, int ldu, int m, double* sum_out)
 {
     MCML_TRY(mvn_loglik_enqueue(c, theta, Us, ldu, m));
-    MCML_HIP(hipMemcpyAsync(sum_out, c.scalars.d(), sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    MCML_TRY(copy_d2h(sum_out, c.scalars.d(), sizeof(double), c.stream));
     MCML_TRY(check_errflag(c, "mvn_ll"));
     return MCML_OK;
 }
@@ -1231,8 +1231,8 @@ int mvn_loglik_batch(Ctx& c, const double* thetas, int k, const double* Us, int 
             MCML_HIP(hipGetLastError());
         }
         double hs[4 * MVN_MAXBATCH]; int hf[MVN_MAXBATCH];
-        MCML_HIP(hipMemcpyAsync(hs, c.bscal.p, sizeof(double) * 4 * kb, hipMemcpyDeviceToHost, c.stream));
-        MCML_HIP(hipMemcpyAsync(hf, bflags, sizeof(int) * kb, hipMemcpyDeviceToHost, c.stream));
+        MCML_TRY(copy_d2h(hs, c.bscal.p, sizeof(double) * 4 * kb, c.stream));
+        MCML_TRY(copy_d2h(hf, bflags, sizeof(int) * kb, c.stream));
         MCML_HIP(hipStreamSynchronize(c.stream));
         for (int j = 0; j < kb; ++j) { sums[j0 + j] = hs[4 * j]; rcs[j0 + j] = hf[j] ? MCML_ENOTPD : MCML_OK; }
     }

@@ -629,7 +629,7 @@ struct NutsRun {
     {
         int* d = c.scalars.as<int>() + 40;
         hipLaunchKernelGGL(k_nuts_count, dim3(1), dim3(256), 0, c.stream, nc.active, C, d);
-        MCML_HIP(hipMemcpyAsync(out, d, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+        MCML_TRY(copy_d2h(out, d, sizeof(int), c.stream));
         MCML_HIP(hipStreamSynchronize(c.stream));
         return MCML_OK;
     }
@@ -696,7 +696,7 @@ struct NutsRun {
                 int* d = c.scalars.as<int>() + 40;
                 int nd = 0;
                 hipLaunchKernelGGL(k_nuts_count, dim3(1), dim3(256), 0, c.stream, nc.hdone, C, d);
-                MCML_HIP(hipMemcpyAsync(&nd, d, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+                MCML_TRY(copy_d2h(&nd, d, sizeof(int), c.stream));
                 MCML_HIP(hipStreamSynchronize(c.stream));
                 if (nd == C) break;
             }
@@ -848,13 +848,13 @@ int nuts_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_nut
         MCML_TRY(launch_gemm<false>(c.stream, Q, ncols, Q, c.L.d(), c.L.ld, samp.d(), samp.ld, epi));
     }
     c.mcols = ncols; c.niter = ncols; c.zu_valid = false; c.uall_valid = false;
-    if (depth_out) MCML_HIP(hipMemcpyAsync(depth_out, d_depth.p, sizeof(int) * (size_t)C * total, hipMemcpyDeviceToHost, c.stream));
-    if (nleap_out) MCML_HIP(hipMemcpyAsync(nleap_out, d_nleap.p, sizeof(int) * (size_t)C * total, hipMemcpyDeviceToHost, c.stream));
-    if (eps_out) MCML_HIP(hipMemcpyAsync(eps_out, d_eps.p, sizeof(double) * (size_t)C * total, hipMemcpyDeviceToHost, c.stream));
-    if (accept_out) MCML_HIP(hipMemcpyAsync(accept_out, d_acc.p, sizeof(double) * (size_t)C * total, hipMemcpyDeviceToHost, c.stream));
+    if (depth_out) MCML_TRY(copy_d2h(depth_out, d_depth.p, sizeof(int) * (size_t)C * total, c.stream));
+    if (nleap_out) MCML_TRY(copy_d2h(nleap_out, d_nleap.p, sizeof(int) * (size_t)C * total, c.stream));
+    if (eps_out) MCML_TRY(copy_d2h(eps_out, d_eps.p, sizeof(double) * (size_t)C * total, c.stream));
+    if (accept_out) MCML_TRY(copy_d2h(accept_out, d_acc.p, sizeof(double) * (size_t)C * total, c.stream));
     double dg[5] = {0, 0, 0, 0, 0};
     hipLaunchKernelGGL(k_nuts_diag, dim3(1), dim3(64), 0, c.stream, r.nc, C, c.scalars.d() + 8);
-    MCML_HIP(hipMemcpyAsync(dg, c.scalars.d() + 8, sizeof dg, hipMemcpyDeviceToHost, c.stream));
+    MCML_TRY(copy_d2h(dg, c.scalars.d() + 8, sizeof dg, c.stream));
     MCML_HIP(hipStreamSynchronize(c.stream));
     c.prof.collect();
     if (diag) {

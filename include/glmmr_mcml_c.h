@@ -225,6 +225,9 @@ int glmmr_mcml_ctx_profile_launches(glmmr_mcml_ctx* ctx, long long* fwd, long lo
  * (dgemm_skinny.h), 1 banded FP64 MFMA kernel (dgemm_band.h), 2 dense direct-to-LDS MFMA kernel (dgemm_dlds.h),
  * 3 register-staged MFMA kernel (dgemm_mfma.h), 4 sparse chain-major operator (hmc_cm.h); -1 none yet */
 int glmmr_mcml_ctx_last_kernels(glmmr_mcml_ctx* ctx, int* fwd, int* bwd);
+/* Host wall-clock time per phase of the MCML iterations run by this process since the last reset (csrc/trace.h):
+ * out8 (nullable) = [sample, beta-step, theta-step, refresh] ms, then the four phase counts.  enable / reset as above. */
+int glmmr_mcml_dbg_phase_ms(int enable, int reset, double* out8);
 int glmmr_mcml_ctx_npar(glmmr_mcml_ctx* ctx);
 
 /* The same drivers on a resident context (what bench.py times). */

@@ -82,7 +82,8 @@ int copy_h2d_2d(void* dev, size_t dpitch, const void* host, size_t hpitch, size_
         const size_t nc = cols - j0 < per ? cols - j0 : per;
         if (hpitch == rowbytes) memcpy(st, (const char*)host + j0 * hpitch, nc * rowbytes);
         else for (size_t j = 0; j < nc; ++j) memcpy(st + j * rowbytes, (const char*)host + (j0 + j) * hpitch, rowbytes);
-        MCML_HIP(hipMemcpy2DAsync((char*)dev + j0 * dpitch, dpitch, st, rowbytes, rowbytes, nc, hipMemcpyHostToDevice, s));
+        if (nc == 1 || dpitch == rowbytes) MCML_HIP(hipMemcpyAsync((char*)dev + j0 * dpitch, st, nc * rowbytes, hipMemcpyHostToDevice, s));
+        else MCML_HIP(hipMemcpy2DAsync((char*)dev + j0 * dpitch, dpitch, st, rowbytes, rowbytes, nc, hipMemcpyHostToDevice, s));
         MCML_HIP(hipStreamSynchronize(s));         // the buffer is reused by the next chunk / the next caller
     }
     return MCML_OK;
@@ -112,7 +113,8 @@ int copy_d2h_2d(void* host, size_t hpitch, const void* dev, size_t dpitch, size_
     const size_t per = STAGE_BYTES / rowbytes;
     for (size_t j0 = 0; j0 < cols; j0 += per) {
         const size_t nc = cols - j0 < per ? cols - j0 : per;
-        MCML_HIP(hipMemcpy2DAsync(st, rowbytes, (const char*)dev + j0 * dpitch, dpitch, rowbytes, nc, hipMemcpyDeviceToHost, s));
+        if (nc == 1 || dpitch == rowbytes) MCML_HIP(hipMemcpyAsync(st, (const char*)dev + j0 * dpitch, nc * rowbytes, hipMemcpyDeviceToHost, s));
+        else MCML_HIP(hipMemcpy2DAsync(st, rowbytes, (const char*)dev + j0 * dpitch, dpitch, rowbytes, nc, hipMemcpyDeviceToHost, s));
         MCML_HIP(hipStreamSynchronize(s));
         if (hpitch == rowbytes) memcpy((char*)host + j0 * hpitch, st, nc * rowbytes);
         else for (size_t j = 0; j < nc; ++j) memcpy((char*)host + (j0 + j) * hpitch, st + j * rowbytes, rowbytes);
@@ -120,8 +122,18 @@ int copy_d2h_2d(void* host, size_t hpitch, const void* dev, size_t dpitch, size_
     return MCML_OK;
 }
 
-int copy_h2d(void* dev, const void* host, size_t bytes, hipStream_t s) { return copy_h2d_2d(dev, bytes, host, bytes, bytes, 1, s); }
-int copy_d2h(void* host, const void* dev, size_t bytes, hipStream_t s) { return copy_d2h_2d(host, bytes, dev, bytes, bytes, 1, s); }
+int copy_h2d(void* dev, const void* host, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return MCML_OK;
+    if (bytes < STAGE_MIN) { MCML_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s)); return MCML_OK; }   // 1-D: the plain call
+    return copy_h2d_2d(dev, bytes, host, bytes, bytes, 1, s);
+}
+int copy_d2h(void* host, const void* dev, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return MCML_OK;
+    if (bytes < STAGE_MIN) { MCML_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s)); return MCML_OK; }
+    return copy_d2h_2d(host, bytes, dev, bytes, bytes, 1, s);
+}
 
 int upload_matrix(DevMat& dst, const double* host, int rows, int cols, int ldh, hipStream_t s)
 {

@@ -45,7 +45,7 @@ struct HostStage {
     void* p = nullptr;
     int get(void** out) {
         if (!p) {
-            hipError_t e = hipHostMalloc(&p, STAGE_BYTES, hipHostMallocDefault);
+            hipError_t e = hipHostMalloc(&p, STAGE_BYTES, hipHostMallocPortable);
             if (e != hipSuccess) { p = nullptr; set_error("hipHostMalloc(%zu) failed: %s", STAGE_BYTES, hipGetErrorString(e)); return MCML_ENOMEM; }
         }
         *out = p;

@@ -378,3 +378,16 @@ extern "C" int glmmr_mcml_dbg_fd_hessian(glmmr_mcml_objective f, void* user, int
     for (int i = 0; i < n * n; ++i) H[i] = h[i];
     return MCML_OK;
 }
+
+extern "C" int glmmr_mcml_dbg_copy_roundtrip(const double* in, long long ld_in, double* out, long long ld_out, long long rows, long long cols)
+{
+    MCML_REQUIRE(in && out && rows > 0 && cols > 0 && ld_in >= rows && ld_out >= rows, "copy_roundtrip: bad arguments");
+    const size_t ldd = (size_t)rows + 3;                 // an odd device pitch
+    DevBuf buf;
+    MCML_TRY(buf.ensure(sizeof(double) * ldd * (size_t)cols));
+    MCML_HIP(hipMemset(buf.p, 0xff, sizeof(double) * ldd * (size_t)cols));
+    MCML_TRY(copy_h2d_2d(buf.p, sizeof(double) * ldd, in, sizeof(double) * (size_t)ld_in, sizeof(double) * (size_t)rows, (size_t)cols, 0));
+    MCML_TRY(copy_d2h_2d(out, sizeof(double) * (size_t)ld_out, buf.p, sizeof(double) * ldd, sizeof(double) * (size_t)rows, (size_t)cols, 0));
+    MCML_HIP(hipDeviceSynchronize());
+    return MCML_OK;
+}

@@ -370,6 +370,9 @@ typedef int (*glmmr_mcml_batch_objective)(const double* X, int n, int k, double*
 int glmmr_mcml_dbg_bobyqa_rounds(glmmr_mcml_batch_objective fb, void* user, int n, const double* x0, const double* lower,
                                  const double* upper, double rhobeg, double rhoend, int maxfun, int width,
                                  double* x_out, double* f_out, int* nfev_out, int* rounds_out);
+/* host -> device -> host through the library's staged copies (csrc/common.hip copy_h2d_2d / copy_d2h_2d): `cols` columns of
+ * `rows` doubles, host pitches ld_in / ld_out (in doubles), a padded pitch on the device */
+int glmmr_mcml_dbg_copy_roundtrip(const double* in, long long ld_in, double* out, long long ld_out, long long rows, long long cols);
 int glmmr_mcml_dbg_fd_hessian(glmmr_mcml_objective f, void* user, int n, const double* x, double ndeps,
                               int usebounds, const double* lower, const double* upper, double* H);
 int glmmr_mcml_dbg_dgemm_bench(int M, int N, int K, int b_nmajor, int iters, int force_tile,

@@ -182,3 +182,21 @@ def test_band_streamed_reduction_is_bit_reproducible():
     g3, _ = _band(np.triu(A.T), B)
     g4, _ = _band(np.triu(A.T), B)
     assert np.array_equal(g3, g4)
+
+
+@pytest.mark.gpu
+def test_staged_host_device_copies_round_trip():
+    """every host <-> device copy above 16 KB goes through the library's pinned staging buffer in chunks (common.hip):
+    small (the runtime's own path), one chunk, many chunks with pitches on both sides, a single column longer than the
+    buffer (piecewise), exactly at the chunk boundaries -- bytes in = bytes out, the host padding untouched"""
+    from glmmrmcml_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    for rows, cols, pad_in, pad_out in ((7, 3, 2, 0), (2048, 1, 0, 0), (1000, 3000, 3, 5), (2 * 1024 * 1024, 1, 0, 0),
+                                        (2 * 1024 * 1024 + 17, 2, 1, 0), (3 * 1024 * 1024 + 5, 1, 0, 0), (4096, 512, 0, 0)):
+        a = np.asfortranarray(rng.normal(size=(rows + pad_in, cols)))
+        out = np.full((rows + pad_out, cols), -7.0, order="F")
+        _lib.check(L.glmmr_mcml_dbg_copy_roundtrip(a.ctypes.data_as(dp), C.c_longlong(rows + pad_in), out.ctypes.data_as(dp),
+                                                   C.c_longlong(rows + pad_out), C.c_longlong(rows), C.c_longlong(cols)))
+        assert np.array_equal(out[:rows], a[:rows]), (rows, cols)
+        assert np.all(out[rows:] == -7.0), (rows, cols)

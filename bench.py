@@ -119,6 +119,8 @@ def other_configs(api, synth, stream, iters=3):
                           seed=7, chains=m, maxfun=40)
                 ctx.profile(enable=True, reset=True)             # markers on for the untimed iteration too: their first use
                 ctx.mcml_full(d["start"], maxiter=1, **kw)        # (and whatever else is first-time) stays out of the timing
+                if os.environ.get("GLMMR_BENCH_SETTLE"):           # experiment: idle time before the timed repetitions
+                    torch.cuda.synchronize(); time.sleep(float(os.environ["GLMMR_BENCH_SETTLE"]))
                 # two repetitions of the same `iters` iterations, both reported: the small configurations are bound by
                 # launches and host wake-ups, and now and then a whole repetition runs ~40 % slower with the same kernel
                 # times ("run-to-run jitter"); ms_per_iter is the faster one

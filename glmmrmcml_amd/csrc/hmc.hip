@@ -756,11 +756,21 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
     int seen_maxs = -1;                         // latest step count actually observed
     const unsigned seq0 = ring.seq + 1;          // sequence number of this call's first proposal
     unsigned seen_seq = seq0 - 1;                // newest proposal of this call whose count has arrived
-    auto harvest = [&]() {                       // newest token of this call in the ring -> seen_seq, seen_maxs
-        for (int i = 0; i < RING; ++i) {
-            const unsigned long long tok = __atomic_load_n(ring.h + i, __ATOMIC_ACQUIRE);
-            const unsigned sq = (unsigned)(tok >> 32);
-            if ((int)(sq - seq0) >= 0 && (int)(sq - seen_seq) > 0) { seen_seq = sq; seen_maxs = (int)(unsigned)tok; }
+    // Speculating costs a whole masked leapfrog step whenever the true count is below the cap (config 5: 290 us against ~30 us
+    // for the wait it saves), so it needs evidence: SPEC_STREAK consecutive proposals at the cap, and the first count below it
+    // ends it.  (With "the last count seen was at the cap" as the only condition a model whose longest chain hovers round the
+    // cap flipped between the two paths by the timing of the read-back: config 5 measured 337-386 ms per iteration from one
+    // process to the next on one box.)
+    constexpr int SPEC_STREAK = 8;
+    int streak = 0;                              // consecutive proposals observed at the cap
+    auto observe = [&](unsigned sq, int v) { seen_seq = sq; seen_maxs = v; streak = (v == o->max_steps) ? streak + 1 : 0; };
+    auto harvest = [&]() {                       // the counts that have arrived, in proposal order (at most AHEAD + 1 are outstanding)
+        for (;;) {
+            const unsigned want = seen_seq + 1;
+            if ((int)(ring.seq - want) < 0) return;                  // nothing launched beyond what has been seen
+            const unsigned long long tok = __atomic_load_n(ring.h + (want % RING), __ATOMIC_ACQUIRE);
+            if ((unsigned)(tok >> 32) != want) return;               // not there yet
+            observe(want, (int)(unsigned)tok);
         }
     };
     bool pending_commit = false;                // sparse operator: the last decisions are applied by the next k_cm_propose
@@ -795,7 +805,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
         const auto tq0 = std::chrono::steady_clock::now();
         harvest();
         int maxs = 0;
-        bool spec = spec_allowed && seen_maxs == o->max_steps;
+        bool spec = spec_allowed && streak >= SPEC_STREAK;
         if (spec) {
             // bounded look-ahead: a count below the cap must be noticed within AHEAD proposals (in the dense path a masked
             // step is a full product).  Plain loads of host memory; a count that does not arrive falls back to the wait below
@@ -804,7 +814,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
                 harvest();
                 if ((int)(seq - seen_seq) > AHEAD && since(tw0) > 2000.0) { spec = false; break; }
             }
-            if (spec && seen_maxs != o->max_steps) spec = false;
+            if (spec && streak < SPEC_STREAK) spec = false;
         }
         if (spec) {
             maxs = o->max_steps;
@@ -816,7 +826,8 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
             const unsigned long long tok = __atomic_load_n(ring.h + slot, __ATOMIC_ACQUIRE);
             MCML_REQUIRE((unsigned)(tok >> 32) == seq, "hmc: the step count of proposal %d did not arrive (token %llx, expected sequence %u)", it, tok, seq);
             maxs = (int)(unsigned)tok;
-            seen_maxs = maxs; seen_seq = seq;
+            harvest();                                               // everything up to and including this proposal, in order
+            MCML_REQUIRE(seen_seq == seq && seen_maxs == maxs, "hmc: step-count ring out of order");
         }
         MCML_REQUIRE(maxs >= 1 && maxs <= o->max_steps, "hmc: step count %d out of range", maxs);
         // kernel timing (bench.py's roofline): every marker between two dependent launches costs ~2.5 us of idle GPU,

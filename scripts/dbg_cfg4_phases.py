@@ -7,6 +7,6 @@ import bench
 from glmmrmcml_amd import api, synth
 stream = torch.cuda.current_stream().cuda_stream
 out = bench.other_configs(api, synth, stream)
-for k in ("cfg2", "cfg4"):
+for k in ("cfg2", "cfg4", "cfg5"):
     o = out[k]
     print(k, [round(x, 1) for x in o["ms_per_iter_reps"]], json.dumps(o["phases_ms_per_iter_reps"]))

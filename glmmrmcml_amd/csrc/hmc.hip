@@ -779,7 +779,7 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
     const auto tc1 = std::chrono::steady_clock::now();
     auto tp_prev = tc1;
     double t_sync = 0, t_slowest = 0; int n_sync = 0;
-    double seg[5] = {0, 0, 0, 0, 0};   // slowest: propose launches | read-back enqueue (speculative) | read-back enqueue (synchronous) | trajectory launches | accept, commit, store
+    double seg[5] = {0, 0, 0, 0, 0};   // slowest enqueue of: [0] propose launches, [1] count look-ahead (speculative path), [3] trajectory launches, [4] accept / commit / store
     auto mark = [&](int k, std::chrono::steady_clock::time_point t) { if (timing) { const double d = since(t); if (d > seg[k]) seg[k] = d; } };
     for (int it = 0; it < total; ++it) {
         const auto tp0 = std::chrono::steady_clock::now();
@@ -898,8 +898,8 @@ int hmc_sample(Ctx& c, const double* beta, double var_par, const glmmr_mcml_hmc_
     MCML_TRY(copy_d2h(dg, c.scalars.d() + 8, sizeof dg, c.stream));
     MCML_HIP(hipStreamSynchronize(c.stream));
     if (timing)
-        fprintf(stderr, "hmc_sample: set-up %.2f ms | %d proposals %.2f ms enqueue (%d synchronous, %.2f ms waiting; slowest proposal %.2f ms: propose %.2f, read-back spec %.2f / sync %.2f, trajectory %.2f, accept %.2f) | tail %.2f ms\n",
-                t_setup, total, t_loop, n_sync, t_sync, t_slowest, seg[0], seg[1], seg[2], seg[3], seg[4], since(tc2));
+        fprintf(stderr, "hmc_sample: set-up %.2f ms | %d proposals %.2f ms enqueue (%d synchronous, %.2f ms waiting; slowest proposal %.2f ms: propose %.2f, count look-ahead %.2f, trajectory %.2f, accept %.2f) | tail %.2f ms\n",
+                t_setup, total, t_loop, n_sync, t_sync, t_slowest, seg[0], seg[1], seg[3], seg[4], since(tc2));
     c.prof.collect();
     if (diag) {
         diag->accept_rate = dg[0] / ((double)C * total);

@@ -110,19 +110,15 @@ struct DevMat {
     DevBuf buf;
     int rows = 0, cols = 0, ld = 0;
     int cols_alloc = 0;     // columns actually allocated (>= cols; round_up(cols, col_align))
-    size_t off = 0;         // bytes between the allocation and element (0, 0) (alloc_at: the sampler staggers its state arrays)
-    int alloc(int r, int c, int col_align = 1) { return alloc_at(r, c, 0, col_align); }
-    // the matrix starts `offset` bytes (a multiple of 256) into its allocation
-    int alloc_at(int r, int c, size_t offset, int col_align = 1) {
+    int alloc(int r, int c, int col_align = 1) {
         int nld = pad_ld(r);
         int ca = round_up(c < 1 ? 1 : c, col_align);
-        if (offset != off) buf.release();           // a different placement is a different buffer
-        MCML_TRY(buf.ensure(sizeof(double) * (size_t)nld * (size_t)ca + offset));
-        rows = r; cols = c; ld = nld; cols_alloc = ca; off = offset;
+        MCML_TRY(buf.ensure(sizeof(double) * (size_t)nld * (size_t)ca));
+        rows = r; cols = c; ld = nld; cols_alloc = ca;
         return MCML_OK;
     }
-    double* d() const { return reinterpret_cast<double*>(static_cast<char*>(buf.p) + off); }
-    double* at(int i, int j) const { return d() + i + (size_t)j * ld; }
+    double* d() const { return buf.d(); }
+    double* at(int i, int j) const { return buf.d() + i + (size_t)j * ld; }
 };
 
 // Host <-> device copies of CALLER (or temporary) host memory.  Everything above a few KB goes through a pinned staging

@@ -430,12 +430,9 @@ static int hmc_alloc(Ctx& c, int C)
     h.cm = c.sp.active;
     if (h.cm) {
         // chain-major (hmc_cm.h): "rows" of the DevMat are the chains
-        // GLMMR_MCML_CM_STAGGER=bytes (experiment): array k of the chain state starts k * bytes into its allocation, so that
-        // equal indices of the arrays a kernel streams together do not share their low address bits
-        static const size_t stg = getenv("GLMMR_MCML_CM_STAGGER") ? (size_t)atol(getenv("GLMMR_MCML_CM_STAGGER")) / 256 * 256 : 0;
-        MCML_TRY(h.V.alloc_at(C, c.Q, 0 * stg)); MCML_TRY(h.R.alloc_at(C, c.Q, 1 * stg)); MCML_TRY(h.UP.alloc_at(C, c.Q, 2 * stg));
-        MCML_TRY(h.GRAD.alloc_at(C, c.Q, 3 * stg)); MCML_TRY(h.GRADP.alloc_at(C, c.Q, 4 * stg));
-        MCML_TRY(h.MU.alloc_at(C, c.n, 5 * stg)); MCML_TRY(h.S.alloc_at(C, c.n, 6 * stg));
+        MCML_TRY(h.V.alloc(C, c.Q)); MCML_TRY(h.R.alloc(C, c.Q)); MCML_TRY(h.UP.alloc(C, c.Q));
+        MCML_TRY(h.GRAD.alloc(C, c.Q)); MCML_TRY(h.GRADP.alloc(C, c.Q));
+        MCML_TRY(h.MU.alloc(C, c.n)); MCML_TRY(h.S.alloc(C, c.n));
         MCML_TRY(h.chain.ensure(sizeof(double) * (size_t)round_up(C, 16) * 8));
         const size_t nchn = (size_t)(c.n + CM_ROWS - 1) / CM_ROWS, nchq = (size_t)(c.Q + cm_qrows(c.Q) - 1) / cm_qrows(c.Q);
         MCML_TRY(h.cm_part.ensure(sizeof(double) * (nchn + 3 * nchq + 4) * (size_t)h.V.ld));

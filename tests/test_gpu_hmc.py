@@ -196,6 +196,38 @@ def test_fused_block_kernel_of_the_factored_operator_is_bit_identical(monkeypatc
     monkeypatch.delenv("GLMMR_MCML_CM_LFUSE", raising=False)
 
 
+def test_speculative_launch_of_the_step_cap_changes_nothing(tmp_path):
+    """while the longest chain sits at the step cap the sampler launches the cap without waiting for the count (hmc.hip: a streak of
+    eight observations at the cap; the count comes back through host memory the device writes); GLMMR_MCML_HMC_SPEC=0 waits for
+    every count.  The switch is read once per process: two child processes, the same draws bit for bit -- dense and sparse
+    operator, step counts pinned at the cap (lambda large) and wandering below it."""
+    import subprocess, sys, os
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from glmmrmcml_amd import api, synth
+out = []
+for gen, kw, lam, ms, ch in ((synth.geospatial, dict(n=300, seed=3), 5.0, 6, 40), (synth.geospatial, dict(n=300, seed=3), 0.3, 10, 40),
+                             (synth.stepped_wedge, dict(ncl=7, nt=5, nind=40), 5.0, 6, 70), (synth.stepped_wedge, dict(ncl=7, nt=5, nind=40), 0.4, 10, 70)):
+    d = gen(**kw)
+    with api.Context(d["cov"], d["data"], d["eff_range"], d["Z"], d["X"], d["y"], d["family"], d["link"]) as ctx:
+        ctx.update_L(d["theta"])
+        diag, flags, probs = ctx.hmc_sample(d["beta"], 1.0, 40, ch * 2, lam, ms, 0.9, seed=5, chains=ch, want_trace=True)
+        out += [ctx.get_u(), flags.astype(float), probs, np.array([diag["leapfrog_total"], diag["max_steps_used"]], float)]
+np.savez(sys.argv[1], *out)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    res = []
+    for spec in ("1", "0"):
+        f = str(tmp_path / ("spec%s.npz" % spec))
+        env = dict(os.environ, GLMMR_MCML_HMC_SPEC=spec)
+        subprocess.run([sys.executable, "-c", code, f], check=True, env=env, timeout=300)
+        with np.load(f) as z:
+            res.append([z[k] for k in sorted(z.files, key=lambda s: int(s.split("_")[1]))])
+    assert len(res[0]) == len(res[1]) == 16
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
 def test_dense_z_sampler_runs_the_direct_to_lds_kernel(orc):
     """a dense, non-identity Z (Householder reflector, bench.py --dense-z): ZL has no structural zeros, more than 16
     chains -> both products run dgemm_dlds_asm_kernel (asserted), chain by chain against the oracle"""

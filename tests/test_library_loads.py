@@ -37,3 +37,11 @@ def test_compute_without_gpu_fails_loudly():
     assert rc != 0
     with pytest.raises(_lib.McmlError):
         _lib.check(rc)
+
+
+def test_phase_clock_is_host_only():
+    """glmmr_mcml_dbg_phase_ms touches no device: enable / read / reset work on a host without a GPU and start at zero"""
+    from glmmrmcml_amd import api
+    api.phase_ms(enable=True, reset=True)
+    got = api.phase_ms(enable=False)
+    assert set(got) == {"sample", "beta_step", "theta_step", "refresh"} and all(v == 0.0 for v in got.values())

@@ -28,6 +28,7 @@ GLMMR_MCML_THETA_SHARD=0 GLMMR_MCML_THETA_BATCH=1 $PY bench.py --steps 3 --warmu
 rocprofv3 --kernel-trace -d $O/kt_rank8 -o b -- $PY bench.py --steps 2 --no-cpu-baseline --as-rank-of 8 > $O/kt_rank8.log 2>&1
 $PY scripts/rocpd_stats.py $O/kt_rank8/b_results.db > $O/bench_rank8_kernel_stats.csv
 $PY bench.py --steps 2 --warmup 1 --no-cpu-baseline --dense-z > $O/bench_densez_line.json 2>/dev/null
+for w in 2 4; do $PY bench.py --steps 3 --no-cpu-baseline --as-rank-of $w > $O/bench_rank${w}_line.json 2>/dev/null; done
 echo "rank8 / dense-z done"
 # 5. theta-step alone, configs 4 and 5
 rocprofv3 --kernel-trace -d $O/kt_mvn -o m -- $PY scripts/time_mvn.py 5000 1024 6 > $O/mvn.log 2>&1
